@@ -1,0 +1,155 @@
+/*
+ * ngsdist_amd.h -- C ABI of the MI355X pairwise-distance engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of fgvieira/ngsDist: the
+ * per-replicate fan-out of gen_dist() over all pairs of individuals.  The
+ * reference has no FFI layer; the seam is the task `void gen_dist_slave(void*)`
+ * handed to threadpool_add() (reference ngsDist.cpp:251, task type
+ * threadpool.h:71-74) around `double gen_dist(params*, uint64_t, uint64_t)`
+ * (ngsDist.hpp:55-56).  Each entry point below names the reference lines it
+ * stands in for.  INTEGRATION.md shows the patch a maintainer of the
+ * reference would apply to call it.
+ *
+ * Conventions
+ *  - plain C, no C++/torch/HIP types in any signature; device pointers and
+ *    streams travel as void*;
+ *  - every function returns NGD_OK (0) or a negative NGD_E_* code and leaves a
+ *    message retrievable with ngd_last_error(); nothing calls exit();
+ *  - the caller owns every host buffer; the engine owns every device buffer
+ *    and keeps no host pointer after a call returns;
+ *  - calls on one engine are not thread-safe (one caller, like main()).
+ *  - pair order is the reference's: row-major upper triangle, i1 < i2
+ *    (ngsDist.cpp:244-245); n_pairs = n_ind*(n_ind-1)/2.
+ *  - results are deterministic run to run (no floating-point atomics).
+ *  - there is no CPU fallback: without a HIP device ngd_create() fails.
+ */
+#ifndef NGSDIST_AMD_H
+#define NGSDIST_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGD_ABI_VERSION 1
+
+#define NGD_OK 0
+#define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
+#define NGD_E_NODEVICE (-2) /* no usable HIP device                        */
+#define NGD_E_HIP (-3)      /* a HIP runtime call failed                   */
+#define NGD_E_NOMEM (-4)    /* host or device allocation failed            */
+#define NGD_E_MODEL (-5)    /* evolutionary model 3..6 (reference: error())*/
+
+/* which kernel serves the per-pair accumulation */
+#define NGD_KERNEL_AUTO 0
+#define NGD_KERNEL_STREAM 1 /* indep: one wavefront per pair, streams 48 B per pair-site */
+#define NGD_KERNEL_MFMA 2   /* indep: FP64 MFMA tiles over the (pair, site) contraction */
+#define NGD_KERNEL_EM_FAITHFUL 3 /* EM: iterates bit-identical to emOptim2.cpp */
+#define NGD_KERNEL_EM_FAST 4     /* EM: division-free power iteration, same stopping rule */
+
+typedef struct ngd_engine ngd_engine;
+
+/* The subset of the reference's `params` (ngsDist.hpp:11-44) that gen_dist()
+ * reads, plus placement. */
+typedef struct ngd_config {
+  uint64_t n_ind;       /* params.n_ind                                       */
+  uint64_t n_sites;     /* params.n_sites of the loaded data set              */
+  double score[9];      /* params.score[g1][g2] row-major, parse_args.cpp:25-27,134-137 */
+  int32_t pairwise_del; /* params.pairwise_del, ngsDist.cpp:335-338           */
+  int32_t indep_geno;   /* params.indep_geno, ngsDist.cpp:348-353             */
+  int32_t device;       /* HIP device ordinal; -1 = current device            */
+  int32_t kernel;       /* NGD_KERNEL_*                                       */
+  uint32_t shard_rank;  /* this engine computes pair tiles t with             */
+  uint32_t shard_world; /*   t % shard_world == shard_rank; 0/1 = everything  */
+  uint32_t reserved[6]; /* must be zero                                       */
+} ngd_config;
+
+/* Per-run device timings (HIP events on the engine's stream). */
+typedef struct ngd_timing {
+  double ms_total;      /* first launch of the run -> results ready           */
+  double ms_accum;      /* the dominant accumulation kernel alone             */
+  double ms_reduce;     /* split-site slab reduction                          */
+  double ms_count;      /* valid-site counting (pairwise deletion only)       */
+  uint64_t pair_sites;  /* (pairs this engine owns) x (sites visited)         */
+  uint64_t launches;    /* accumulation kernel launches in the run            */
+} ngd_timing;
+
+const char *ngd_last_error(void);
+int ngd_abi_version(void);
+/* number of visible HIP devices (0 if none); never fails */
+int ngd_device_count(void);
+
+/* Engine lifetime.  Stands in for the thread pool + pth_struct array set up in
+ * ngsDist.cpp:197-208 and torn down in :291-306. */
+int ngd_create(const ngd_config *cfg, ngd_engine **out);
+void ngd_destroy(ngd_engine *e);
+
+/* Input: the prepared, NORMAL-space array gen_dist() reads (params.geno_lkl
+ * after ngsDist.cpp:165-174).  Two host layouts are accepted:
+ *   ngd_upload_sites     p[(s*n_ind + i)*3 + g], sites s0 .. s0+n-1 -- the
+ *                        order of the binary file (read_data.cpp:28-31), so a
+ *                        host can stream a file through in chunks;
+ *   ngd_upload_ind_major p[(i*n_sites + s)*3 + g] -- the reference's in-memory
+ *                        order in_geno_lkl[i][s][g], whole data set at once.
+ * ngd_commit() ends the upload (derives the per-individual missing-site masks
+ * of gen_func.cpp:862-868 and the score-weighted operand).  After commit the
+ * data set is immutable; bootstrap never moves data (see ngd_run). */
+int ngd_upload_sites(ngd_engine *e, const double *p, uint64_t s0, uint64_t n);
+int ngd_upload_ind_major(ngd_engine *e, const double *p);
+int ngd_commit(ngd_engine *e);
+
+/* Test/bench input: fills the engine with this repository's counter-based
+ * synthetic data set (bit-identical to oracle ngo_synth_one) on
+ * the device, then commits.  Not part of the reference's surface. */
+int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac);
+
+/* One replicate = everything between rnd_map_data() and the matrix print:
+ * the `for i1<i2: threadpool_add(gen_dist_slave)` + threadpool_wait block,
+ * ngsDist.cpp:244-269, with gen_dist()'s loop :333-364.
+ *   block_map == NULL : the full data set (rep 0), n_blocks/block_size ignored;
+ *   else                block_map[b] (b < n_blocks) is the source block that
+ *                       rnd_map_data (ngsDist.cpp:416-437) puts at block b,
+ *                       i.e. floor(draw_rnd(0, n_blocks)); sites at or beyond
+ *                       n_blocks*block_size are not visited (:236).
+ * Outputs (host, caller-owned, n_pairs entries each, either may be NULL):
+ *   sum[k] : gen_dist()'s `dist` before ngsDist.cpp:376;
+ *   cnt[k] : gen_dist()'s `cnt` before the tot_sites override (:372-373).
+ * Pairs outside this engine's shard are returned as 0 / 0. */
+int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
+            uint64_t block_size, double *sum, uint64_t *cnt);
+
+/* Same, but results stay on the device: d_sum (double[n_pairs]) and d_cnt
+ * (uint64_t[n_pairs]) are DEVICE pointers owned by the caller (e.g. the
+ * storage of a torch tensor used for the RCCL gather).  Returns after the
+ * engine's stream has finished. */
+int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
+                   uint64_t block_size, void *d_sum, void *d_cnt);
+
+int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
+
+/* The tail of gen_dist(), ngsDist.cpp:372-401, on the HOST with the host's
+ * libm so that -0.0 / inf / nan cells print exactly as the reference's do:
+ *   cnt = tot_sites if tot_sites > 0; d = sum/cnt;
+ *   model 0: d; 1: -log(1-d); 2: -log(1-d*4/3)*3/4; 3..6: NGD_E_MODEL. */
+int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs,
+               uint64_t tot_sites, uint64_t evol_model, double *dist);
+
+/* Bootstrap block map exactly as the reference draws it (gsl_rng_taus seeded
+ * with --seed, ngsDist.cpp:179-180; one draw per block, :421-423).  The state
+ * is three uint32 carried across replicates by the caller. */
+void ngd_taus_seed(uint32_t state[3], uint64_t seed);
+uint32_t ngd_taus_get(uint32_t state[3]);
+double ngd_taus_uniform(uint32_t state[3]);
+void ngd_boot_block_map(uint32_t state[3], uint64_t n_blocks, uint64_t *block_map);
+
+/* geometry helpers */
+uint64_t ngd_n_pairs(uint64_t n_ind);
+uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
+/* bytes of device memory the engine holds for this configuration */
+uint64_t ngd_device_bytes(const ngd_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGSDIST_AMD_H */

@@ -1,0 +1,103 @@
+"""Loads libngsdist_amd.so (the HIP engine behind include/ngsdist_amd.h).
+
+There is no fallback: if the library is missing or will not load, importing
+fails loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C ngsdist_amd/csrc`.
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libngsdist_amd.so")
+
+
+class NgdConfig(C.Structure):
+    _fields_ = [
+        ("n_ind", C.c_uint64),
+        ("n_sites", C.c_uint64),
+        ("score", C.c_double * 9),
+        ("pairwise_del", C.c_int32),
+        ("indep_geno", C.c_int32),
+        ("device", C.c_int32),
+        ("kernel", C.c_int32),
+        ("shard_rank", C.c_uint32),
+        ("shard_world", C.c_uint32),
+        ("reserved", C.c_uint32 * 6),
+    ]
+
+
+class NgdTiming(C.Structure):
+    _fields_ = [
+        ("ms_total", C.c_double),
+        ("ms_accum", C.c_double),
+        ("ms_reduce", C.c_double),
+        ("ms_count", C.c_double),
+        ("pair_sites", C.c_uint64),
+        ("launches", C.c_uint64),
+    ]
+
+
+# every symbol include/ngsdist_amd.h declares (tests/test_abi.py checks the header against this)
+EXPORTS = [
+    "ngd_last_error", "ngd_abi_version", "ngd_device_count", "ngd_create", "ngd_destroy",
+    "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_synth_fill", "ngd_run",
+    "ngd_run_device", "ngd_last_timing", "ngd_finish", "ngd_taus_seed", "ngd_taus_get",
+    "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes",
+]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "ngsdist_amd: %s is missing -- the HIP engine was not built (run __graft_entry__.build() "
+            "or `make -C ngsdist_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: if PyTorch is present, let ITS libamdhip64.so.7 be
+    # the one already mapped when our DT_NEEDED entry of the same soname is resolved,
+    # so device pointers / streams can be shared with torch (RCCL gather in bench.py).
+    if "torch" not in sys.modules and not os.environ.get("NGD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    try:
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise ImportError("ngsdist_amd: cannot load %s: %s (no CPU fallback)" % (LIB_PATH, exc))
+    vp, dp, u64, u64p = C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64)
+    u32p = C.POINTER(C.c_uint32)
+    L.ngd_last_error.restype = C.c_char_p
+    L.ngd_abi_version.restype = C.c_int
+    L.ngd_device_count.restype = C.c_int
+    L.ngd_create.argtypes = [C.POINTER(NgdConfig), C.POINTER(vp)]
+    L.ngd_destroy.argtypes = [vp]
+    L.ngd_destroy.restype = None
+    L.ngd_upload_sites.argtypes = [vp, dp, u64, u64]
+    L.ngd_upload_ind_major.argtypes = [vp, dp]
+    L.ngd_commit.argtypes = [vp]
+    L.ngd_synth_fill.argtypes = [vp, u64, C.c_double]
+    L.ngd_run.argtypes = [vp, u64p, u64, u64, dp, u64p]
+    L.ngd_run_device.argtypes = [vp, u64p, u64, u64, vp, vp]
+    L.ngd_last_timing.argtypes = [vp, C.POINTER(NgdTiming)]
+    L.ngd_finish.argtypes = [dp, u64p, u64, u64, u64, dp]
+    L.ngd_taus_seed.argtypes = [u32p, u64]
+    L.ngd_taus_seed.restype = None
+    L.ngd_taus_get.argtypes = [u32p]
+    L.ngd_taus_get.restype = C.c_uint32
+    L.ngd_taus_uniform.argtypes = [u32p]
+    L.ngd_taus_uniform.restype = C.c_double
+    L.ngd_boot_block_map.argtypes = [u32p, u64, u64p]
+    L.ngd_boot_block_map.restype = None
+    L.ngd_n_pairs.argtypes = [u64]
+    L.ngd_n_pairs.restype = u64
+    L.ngd_pair_index.argtypes = [u64, u64, u64]
+    L.ngd_pair_index.restype = u64
+    L.ngd_device_bytes.argtypes = [vp]
+    L.ngd_device_bytes.restype = u64
+    _lib = L
+    return L

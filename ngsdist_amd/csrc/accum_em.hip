@@ -1,0 +1,171 @@
+// accum_em.hip -- gen_dist() without --indep_geno: per (pair, site) the 9-cell
+// joint-genotype EM of the reference's emOptim2.cpp (em2 :112-135, emStep2
+// :91-109, lik2 :77-89, normalize :69-75; called from ngsDist.cpp:340-353 with
+// one site, start 1/9, tole 0.001, maxIter 50), then the score-weighted sum.
+//
+// Workgroup = 256 threads = one 16x16 tile of pairs x one slice of sites; each
+// thread owns one pair and walks the slice's sites in order, so the per-slice
+// sum is a plain sequential accumulation like the reference's.  The operand
+// reads are the fragment-major image's 128-byte runs (16 consecutive
+// individuals of one (site, genotype)); the path is FP64-VALU bound.
+//
+// Two device forms of the same EM:
+//  * faithful: every multiply/add/divide of emStep2/normalize/lik2 in the
+//    reference's order (IEEE double, no contraction), so the iterates are
+//    bit-identical to the CPU's; only log() is the device's (<= 1 ulp), which
+//    enters the stopping test alone.
+//  * fast: the single-site EM has the closed-form iterate sfs_t = a^t / S_t with
+//    a_k = GL1[x]*GL2[y] and S_t = SUM_k a_k^t, and lik_t = log(S_{t+1}/S_t); the
+//    stopping rule |lik_t - lik_{t-1}| < tole becomes S_{t+1}*S_{t-1} < e^tole * S_t^2
+//    (the likelihood is non-decreasing).  No divide and no log per iteration;
+//    one divide per site.  Agrees with the faithful form to ~1e-14 relative.
+#include "ngd_internal.h"
+
+namespace {
+
+constexpr double TOLE = 0.001;  // ngsDist.cpp:349
+constexpr int MAX_ITER = 50;    // ngsDist.cpp:349
+
+__device__ __forceinline__ double lik2(const double *sfs, const double *g1, const double *g2) {
+  double tmp = 0;
+#pragma unroll
+  for (int x = 0; x < 3; x++)
+#pragma unroll
+    for (int y = 0; y < 3; y++) tmp += sfs[3 * x + y] * g1[x] * g2[y];
+  return 0 + log(tmp);
+}
+
+__device__ __forceinline__ void normalize9(double *t) {
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) s += t[i];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] /= s;
+}
+
+// returns SUM_k score_k * sfs_k accumulated INTO acc in the reference's order
+__device__ __forceinline__ double site_faithful(const double *g1, const double *g2, const ngd_score &sc,
+                                                double acc, double w, bool weighted) {
+  double sfs[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) sfs[k] = (double)1 / 9;
+  double oldLik = lik2(sfs, g1, g2);
+  for (int it = 0; it < MAX_ITER; it++) {
+    double inner[9];
+#pragma unroll
+    for (int x = 0; x < 3; x++)
+#pragma unroll
+      for (int y = 0; y < 3; y++) inner[3 * x + y] = sfs[3 * x + y] * g1[x] * g2[y];
+    normalize9(inner);
+#pragma unroll
+    for (int k = 0; k < 9; k++) sfs[k] = 0.0 + inner[k];
+    normalize9(sfs);
+    double lik = lik2(sfs, g1, g2);
+    bool stop = fabs(lik - oldLik) < TOLE;
+    oldLik = lik;
+    if (stop) break;
+  }
+  if (weighted) {
+    double c = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) c += sc.v[k] * sfs[k];
+    return acc + c * w;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc += sc.v[k] * sfs[k];
+  return acc;
+}
+
+__device__ __forceinline__ double site_fast(const double *g1, const double *g2, const ngd_score &sc,
+                                            double acc, double w) {
+  const double E = 1.0010005001667084;  // exp(0.001)
+  double a[9], u[9];
+#pragma unroll
+  for (int x = 0; x < 3; x++)
+#pragma unroll
+    for (int y = 0; y < 3; y++) a[3 * x + y] = g1[x] * g2[y];
+  double Sm = 9.0, Sc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { u[k] = a[k]; Sc += a[k]; }
+  for (int t = 1;; t++) {
+    double un[9], Sn = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { un[k] = u[k] * a[k]; Sn += un[k]; }
+    bool stop = (Sn * Sm < E * (Sc * Sc)) || t == MAX_ITER;
+    if (stop) break;
+#pragma unroll
+    for (int k = 0; k < 9; k++) u[k] = un[k];
+    Sm = Sc; Sc = Sn;
+  }
+  double c = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) c += sc.v[k] * u[k];
+  return acc + (c / Sc) * w;
+}
+
+template <bool FAST, bool WEIGHTED, bool PDEL>
+__global__ __launch_bounds__(256) void k_accum_em(const double *__restrict__ PA,
+                                                   const uint32_t *__restrict__ ws, ngd_score sc,
+                                                   const ngd_tile *__restrict__ tiles, uint32_t n_tiles,
+                                                   uint32_t n_ig, uint32_t n_pad, uint64_t n_ind,
+                                                   uint64_t n_sites_eff, uint64_t sites_per_slice,
+                                                   double *__restrict__ slab) {
+  const uint32_t tile = blockIdx.x % n_tiles;
+  const uint32_t ks = blockIdx.x / n_tiles;
+  const uint32_t ig = tiles[tile].ti, jg = tiles[tile].tj;
+  const uint32_t i = ig * 16 + (threadIdx.x >> 4);
+  const uint32_t j = jg * 16 + (threadIdx.x & 15);
+  const bool valid = i < j && j < n_ind;
+  const uint64_t s0 = (uint64_t)ks * sites_per_slice;
+  uint64_t s1 = s0 + sites_per_slice;
+  if (s1 > n_sites_eff) s1 = n_sites_eff;
+
+  const uint64_t kstride = (uint64_t)n_ig * 64;  // doubles between consecutive k-groups
+  double acc = 0;
+  if (valid) {
+    const double *pi = PA + (uint64_t)ig * 64 + (i & 15);
+    const double *pj = PA + (uint64_t)jg * 64 + (j & 15);
+    for (uint64_t s = s0; s < s1; s++) {
+      double w = 1.0;
+      if (WEIGHTED) {
+        const uint32_t m = ws[s];
+        if (m == 0) continue;  // site not drawn in this replicate (uniform across the workgroup)
+        w = (double)m;
+      }
+      double g1[3], g2[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const uint64_t k = 3 * s + c;
+        const uint64_t off = (k >> 2) * kstride + (k & 3) * 16;
+        g1[c] = pi[off];
+        g2[c] = pj[off];
+      }
+      if (PDEL && (ngd_miss(g1[0], g1[1], g1[2]) || ngd_miss(g2[0], g2[1], g2[2]))) continue;
+      if (FAST) acc = site_fast(g1, g2, sc, acc, w);
+      else acc = site_faithful(g1, g2, sc, acc, w, WEIGHTED);
+    }
+  }
+  slab[((uint64_t)ks * n_pad + i) * n_pad + j] = acc;
+}
+
+}  // namespace
+
+void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
+                         uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,
+                         const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
+                         uint64_t sites_per_slice, double *slab) {
+  if (!n_tiles16) return;
+  dim3 grid(n_tiles16 * n_ks), block(256);
+#define NGD_EM(F, W, P)                                                                              \
+  hipLaunchKernelGGL((k_accum_em<F, W, P>), grid, block, 0, st, PA, d_ws, score, d_tiles16, n_tiles16, \
+                     g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab)
+  const bool w = d_ws != nullptr, p = pairwise_del != 0;
+  if (fast) {
+    if (w) { if (p) NGD_EM(true, true, true); else NGD_EM(true, true, false); }
+    else   { if (p) NGD_EM(true, false, true); else NGD_EM(true, false, false); }
+  } else {
+    if (w) { if (p) NGD_EM(false, true, true); else NGD_EM(false, true, false); }
+    else   { if (p) NGD_EM(false, false, true); else NGD_EM(false, false, false); }
+  }
+#undef NGD_EM
+}

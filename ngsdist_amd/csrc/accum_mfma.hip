@@ -1,0 +1,164 @@
+// accum_mfma.hip -- the --indep_geno accumulation of gen_dist() (reference
+// ngsDist.cpp:333-364 with the product branch of :353) for ALL pairs at once.
+//
+// With independent genotypes the per-pair sum is a contraction over k = (site,
+// genotype):   sum[i1][i2] = SUM_k P[i1][k] * Q[i2][k],   Q = score . P per site
+// (the nine score-weighted products of :351-353 regrouped as three), i.e. the
+// upper triangle of P.Q^T with K = 3*n_sites.  Streaming it pair by pair moves
+// 48 B per pair-site (accum_stream.hip); tiling it re-uses every operand 128
+// times and leaves the FP64 pipe as the only limit.  On gfx950 the FP64 matrix
+// rate equals the FP64 vector rate, but v_mfma_f64_16x16x4_f64 takes ONE double
+// per lane per operand for 1024 FMAs, so operand delivery (VGPR/LDS/L1 traffic)
+// drops 16x versus v_fma_f64 register tiles.
+//
+// Workgroup = 4 wavefronts = one 128x128 pair tile x one slice of k.
+// Wavefront  = 64x64 sub-tile = 4x4 MFMA tiles, 16 accumulators of 4 doubles.
+// Operands come straight from the fragment-major images (ngd_internal.h): one
+// coalesced 512-B global load per 16x4 operand, software-pipelined DEPTH k-groups
+// ahead in registers; the 4 wavefronts of a tile share operands through L1/L2.
+// Block ids are dealt so that all tiles of one k-slice run on one XCD at about
+// the same time, which keeps the slice's operand panel in that XCD's L2.
+// Slices are written as slabs and summed in fixed order by reduce.hip
+// (deterministic; no floating-point atomics).
+#include "ngd_internal.h"
+
+namespace {
+
+constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
+constexpr int DEPTH = 4;       // k-groups in flight per wavefront (<= NGD_KG_TAIL)
+static_assert(DEPTH <= NGD_KG_TAIL, "tail padding must cover the run-ahead");
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256, 2) void k_accum_mfma(
+    const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
+    const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad,
+    uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
+  // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
+  const uint32_t b = blockIdx.x;
+  const uint32_t xcd = b & 7u, q = b >> 3;
+  const uint32_t tile = q % n_tiles;
+  const uint32_t ks = (q / n_tiles) * 8u + xcd;
+  const uint32_t ti = tiles[tile].ti, tj = tiles[tile].tj;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wi = wave >> 1, wj = wave & 1;
+  if (ti == tj && wi > wj) return;  // strictly-lower sub-tile of a diagonal tile: never read
+  const uint32_t ig0 = ti * NGD_IG_PER_TILE + wi * WM;
+  const uint32_t jg0 = tj * NGD_IG_PER_TILE + wj * WN;
+
+  const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
+  uint64_t kg1 = kg0 + kg_per_slice;
+  if (kg1 > n_kg) kg1 = n_kg;
+
+  ngd_d4 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; m++)
+#pragma unroll
+    for (int n = 0; n < WN; n++) acc[m][n] = (ngd_d4){0, 0, 0, 0};
+
+  const uint64_t kstride = (uint64_t)n_ig * 64;
+  const double *pa = PA + (uint64_t)ig0 * 64 + lane;
+  const double *pb = QB + (uint64_t)jg0 * 64 + lane;
+
+  double a[DEPTH][WM], bq[DEPTH][WN];
+  uint32_t wq[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++) wq[d] = 0;
+
+  // The operand pipeline is issued by hand.  hipcc's waitcnt pass puts a full
+  // `s_waitcnt vmcnt(0)` at the head of any loop whose loads are consumed one
+  // trip later, which would expose the whole memory latency once per trip; so the
+  // loads are inline asm (invisible to that pass) and every consume step waits
+  // with an exact count: the LPF*(DEPTH-1) youngest loads may stay in flight.
+  // Each wait names the registers it guards as "+v" operands, which pins the
+  // MFMAs that read them behind it.
+  //
+  // Loads are unconditional: slices are whole multiples of DEPTH k-groups and the
+  // images carry DEPTH zeroed k-groups of tail padding, so the run-ahead past the
+  // slice end stays in bounds and is never consumed (it is drained before the
+  // epilogue, because the compiler is free to re-use those registers there).
+  constexpr int LPF = WM + WN + (WEIGHTED ? 1 : 0);  // loads per fetch
+  auto fetch = [&](int d, uint64_t kg) {
+    const double *xa = pa + kg * kstride;
+    const double *xb = pb + kg * kstride;
+    asm volatile(
+        "global_load_dwordx2 %0, %4, off\n\t"
+        "global_load_dwordx2 %1, %4, off offset:512\n\t"
+        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+        "global_load_dwordx2 %3, %4, off offset:1536"
+        : "=&v"(a[d][0]), "=&v"(a[d][1]), "=&v"(a[d][2]), "=&v"(a[d][3])
+        : "v"(xa));
+    asm volatile(
+        "global_load_dwordx2 %0, %4, off\n\t"
+        "global_load_dwordx2 %1, %4, off offset:512\n\t"
+        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
+        "global_load_dwordx2 %3, %4, off offset:1536"
+        : "=&v"(bq[d][0]), "=&v"(bq[d][1]), "=&v"(bq[d][2]), "=&v"(bq[d][3])
+        : "v"(xb));
+    if (WEIGHTED) {
+      const uint32_t *xw = ws + (kg * 4 + (uint64_t)(lane >> 4)) / 3;
+      asm volatile("global_load_dword %0, %1, off" : "=&v"(wq[d]) : "v"(xw));
+    }
+  };
+  auto arrive = [&](int d) {  // wait until fetch #d (the oldest outstanding) has landed
+    asm volatile("s_waitcnt vmcnt(%9)"
+                 : "+v"(a[d][0]), "+v"(a[d][1]), "+v"(a[d][2]), "+v"(a[d][3]), "+v"(bq[d][0]),
+                   "+v"(bq[d][1]), "+v"(bq[d][2]), "+v"(bq[d][3]), "+v"(wq[d])
+                 : "n"(LPF * (DEPTH - 1)));
+  };
+  static_assert(WM == 4 && WN == 4, "the asm fetch is written for 4+4 operands");
+
+  if (kg0 < kg1) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fetch(d, kg0 + d);
+
+    for (uint64_t kg = kg0; kg < kg1; kg += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; d++) {
+        arrive(d);
+        if (WEIGHTED) {  // bootstrap multiplicity of the site (ngsDist.cpp:426-434)
+          const double w = (double)wq[d];
+#pragma unroll
+          for (int m = 0; m < WM; m++) a[d][m] *= w;
+        }
+#pragma unroll
+        for (int m = 0; m < WM; m++)
+#pragma unroll
+          for (int n = 0; n < WN; n++)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
+        fetch(d, kg + d + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*r
+  double *out = slab + (uint64_t)ks * n_pad * n_pad;
+#pragma unroll
+  for (int m = 0; m < WM; m++)
+#pragma unroll
+    for (int n = 0; n < WN; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
+        const uint32_t j = (jg0 + n) * 16 + (lane & 15);
+        out[(uint64_t)i * n_pad + j] = acc[m][n][r];
+      }
+}
+
+}  // namespace
+
+void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
+                           const uint32_t *d_ws, const ngd_tile *d_tiles, uint32_t n_tiles,
+                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
+  if (!n_tiles) return;
+  dim3 grid(n_tiles * n_ks), block(256);  // n_ks is a multiple of 8 (see the deal above)
+  if (d_ws)
+    hipLaunchKernelGGL((k_accum_mfma<true>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, g.n_ig,
+                       g.n_pad, kg_per_slice, n_kg_eff, slab);
+  else
+    hipLaunchKernelGGL((k_accum_mfma<false>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles,
+                       g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);
+}

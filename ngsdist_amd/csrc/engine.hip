@@ -1,0 +1,430 @@
+// engine.hip -- the C ABI of include/ngsdist_amd.h: device-resident data set,
+// shard bookkeeping and the per-replicate launch sequence that stands in for
+// the reference's `for i1<i2: threadpool_add(gen_dist_slave)` block
+// (ngsDist.cpp:244-269).  There is no CPU fallback anywhere in this file: if
+// HIP is unusable every entry point fails with an error code.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ngd_internal.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(call)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (call);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(_e == hipErrorOutOfMemory ? NGD_E_NOMEM : NGD_E_HIP,                     \
+                  std::string(#call) + ": " + hipGetErrorString(_e));                      \
+  } while (0)
+
+struct ngd_engine {
+  ngd_config cfg{};
+  ngd_geom g{};
+  ngd_score sc{};
+  int device = 0;
+  int kernel = 0;  // resolved NGD_KERNEL_*
+  hipStream_t st = nullptr;
+  hipEvent_t ev[5] = {};
+  // resident data set
+  double *PA = nullptr, *QB = nullptr, *PI = nullptr;
+  unsigned long long *mask = nullptr, *planes = nullptr;
+  // bootstrap
+  uint64_t *d_block_map = nullptr;
+  uint32_t *d_mult = nullptr, *d_ws = nullptr;
+  uint64_t cap_blocks = 0;
+  // shard
+  ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
+  uint32_t n_tiles = 0, n_tiles16 = 0;
+  uint64_t *d_pairs = nullptr;
+  uint64_t n_owned_pairs = 0;
+  // scratch + results
+  double *slab = nullptr;
+  uint32_t n_ks = 0;
+  uint64_t per_slice = 0;
+  double *d_sum = nullptr;
+  unsigned long long *d_cnt = nullptr;
+  double *staging = nullptr;
+  uint64_t staging_sites = 0;
+  bool committed = false;
+  uint64_t dev_bytes = 0;
+  ngd_timing timing{};
+};
+
+template <typename T>
+static int dev_alloc(ngd_engine *e, T **p, uint64_t count, bool zero) {
+  *p = nullptr;
+  if (!count) return NGD_OK;
+  HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+  e->dev_bytes += count * sizeof(T);
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), e->st));
+  return NGD_OK;
+}
+
+static uint64_t env_u64(const char *name, uint64_t dflt) {
+  const char *v = getenv(name);
+  return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
+}
+
+extern "C" {
+
+const char *ngd_last_error(void) { return g_err.c_str(); }
+int ngd_abi_version(void) { return NGD_ABI_VERSION; }
+
+int ngd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+uint64_t ngd_n_pairs(uint64_t n_ind) { return n_ind * (n_ind - 1) / 2; }
+uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2) { return ngd_pair_idx(n_ind, i1, i2); }
+uint64_t ngd_device_bytes(const ngd_engine *e) { return e ? e->dev_bytes : 0; }
+
+void ngd_destroy(ngd_engine *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  if (e->st) hipStreamSynchronize(e->st);
+  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_block_map, e->d_mult, e->d_ws,
+                  e->d_tiles, e->d_tiles16, e->d_pairs, e->slab, e->d_sum, e->d_cnt, e->staging};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  for (auto &v : e->ev)
+    if (v) hipEventDestroy(v);
+  if (e->st) hipStreamDestroy(e->st);
+  delete e;
+}
+
+int ngd_create(const ngd_config *cfg, ngd_engine **out) {
+  if (!cfg || !out) return fail(NGD_E_INVALID, "ngd_create: null argument");
+  *out = nullptr;
+  if (cfg->n_ind < 2) return fail(NGD_E_INVALID, "ngd_create: need at least 2 individuals");
+  if (cfg->n_sites < 1) return fail(NGD_E_INVALID, "ngd_create: need at least 1 site");
+  if (cfg->n_ind > 60000) return fail(NGD_E_INVALID, "ngd_create: n_ind > 60000 not supported");
+  for (uint32_t r : cfg->reserved)
+    if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
+  const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
+  if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
+
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+    return fail(NGD_E_NODEVICE, "ngd_create: no HIP device (this engine has no CPU path)");
+  int dev = cfg->device;
+  if (dev < 0) HIPCHK(hipGetDevice(&dev));
+  if (dev >= n_dev) return fail(NGD_E_NODEVICE, "ngd_create: device ordinal out of range");
+  HIPCHK(hipSetDevice(dev));
+
+  int kernel = cfg->kernel;
+  if (cfg->indep_geno) {
+    if (kernel == NGD_KERNEL_AUTO) kernel = NGD_KERNEL_MFMA;
+    if (kernel != NGD_KERNEL_MFMA && kernel != NGD_KERNEL_STREAM)
+      return fail(NGD_E_INVALID, "ngd_create: kernel does not serve --indep_geno");
+  } else {
+    if (kernel == NGD_KERNEL_AUTO) kernel = NGD_KERNEL_EM_FAST;
+    if (kernel != NGD_KERNEL_EM_FAST && kernel != NGD_KERNEL_EM_FAITHFUL)
+      return fail(NGD_E_INVALID, "ngd_create: kernel does not serve the EM path");
+  }
+
+  ngd_engine *e = new (std::nothrow) ngd_engine();
+  if (!e) return fail(NGD_E_NOMEM, "ngd_create: host allocation failed");
+  e->cfg = *cfg;
+  e->cfg.shard_world = world;
+  e->device = dev;
+  e->kernel = kernel;
+  memcpy(e->sc.v, cfg->score, sizeof(e->sc.v));
+
+  ngd_geom &g = e->g;
+  g.n_ind = cfg->n_ind;
+  g.n_sites = cfg->n_sites;
+  g.n_sites_pad = (cfg->n_sites + 15) / 16 * 16;  // -> n_kg is a multiple of 12
+  g.n_kg = 3 * g.n_sites_pad / 4;
+  g.n_t = (uint32_t)((cfg->n_ind + NGD_TILE - 1) / NGD_TILE);
+  g.n_pad = g.n_t * NGD_TILE;
+  g.n_ig = g.n_pad / NGD_IG;
+  g.n_words = (uint32_t)((cfg->n_sites + 63) / 64);
+
+  int rc = NGD_OK;
+  auto bail = [&](int code) {
+    std::string keep = g_err;
+    ngd_destroy(e);
+    g_err = keep;
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(NGD_E_HIP, "ngd_create: hipStreamCreate failed"));
+  for (auto &v : e->ev)
+    if (hipEventCreate(&v) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
+
+  // ---- shard: upper-triangular 128-tiles dealt round-robin over ranks ----
+  std::vector<ngd_tile> tiles, tiles16;
+  std::vector<uint64_t> pairs;
+  uint32_t tid = 0;
+  for (uint32_t ti = 0; ti < g.n_t; ti++)
+    for (uint32_t tj = ti; tj < g.n_t; tj++, tid++) {
+      if (tid % world != cfg->shard_rank) continue;
+      tiles.push_back({(uint16_t)ti, (uint16_t)tj});
+      for (uint32_t a = 0; a < NGD_IG_PER_TILE; a++)
+        for (uint32_t b = 0; b < NGD_IG_PER_TILE; b++) {
+          uint32_t ig = ti * NGD_IG_PER_TILE + a, jg = tj * NGD_IG_PER_TILE + b;
+          if (ig > jg) continue;                                  // strictly lower: no i<j pair
+          if ((uint64_t)ig * 16 >= g.n_ind || (uint64_t)jg * 16 >= g.n_ind) continue;  // all padding
+          tiles16.push_back({(uint16_t)ig, (uint16_t)jg});
+        }
+    }
+  e->n_tiles = (uint32_t)tiles.size();
+  e->n_tiles16 = (uint32_t)tiles16.size();
+  if (kernel == NGD_KERNEL_STREAM && world > 1) {
+    for (const ngd_tile &t : tiles)
+      for (uint64_t i = (uint64_t)t.ti * NGD_TILE; i < std::min<uint64_t>(g.n_ind, (t.ti + 1ull) * NGD_TILE); i++)
+        for (uint64_t j = std::max<uint64_t>(i + 1, (uint64_t)t.tj * NGD_TILE);
+             j < std::min<uint64_t>(g.n_ind, (t.tj + 1ull) * NGD_TILE); j++)
+          pairs.push_back(ngd_pair_idx(g.n_ind, i, j));
+    std::sort(pairs.begin(), pairs.end());
+    e->n_owned_pairs = pairs.size();
+  } else {
+    e->n_owned_pairs = 0;
+    for (const ngd_tile &t : tiles)
+      for (uint64_t i = (uint64_t)t.ti * NGD_TILE; i < std::min<uint64_t>(g.n_ind, (t.ti + 1ull) * NGD_TILE); i++) {
+        uint64_t jlo = std::max<uint64_t>(i + 1, (uint64_t)t.tj * NGD_TILE);
+        uint64_t jhi = std::min<uint64_t>(g.n_ind, (t.tj + 1ull) * NGD_TILE);
+        if (jhi > jlo) e->n_owned_pairs += jhi - jlo;
+      }
+  }
+
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
+  // + NGD_KG_TAIL zeroed k-groups: the MFMA kernel's operand pipeline runs ahead of its slice
+  const uint64_t frag_elems = (g.n_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64;
+#define TRY(x)                       \
+  do {                               \
+    rc = (x);                        \
+    if (rc != NGD_OK) return bail(rc); \
+  } while (0)
+  TRY(dev_alloc(e, &e->d_tiles, tiles.size(), false));
+  TRY(dev_alloc(e, &e->d_tiles16, tiles16.size(), false));
+  TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
+  if (!tiles.empty())
+    if (hipMemcpy(e->d_tiles, tiles.data(), tiles.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
+  if (!tiles16.empty())
+    if (hipMemcpy(e->d_tiles16, tiles16.data(), tiles16.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
+  if (!pairs.empty())
+    if (hipMemcpy(e->d_pairs, pairs.data(), pairs.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: pair list upload failed"));
+
+  // ---- resident images (zero-filled: padding individuals/sites contribute nothing) ----
+  if (kernel == NGD_KERNEL_STREAM) {
+    TRY(dev_alloc(e, &e->PI, g.n_ind * g.n_sites_pad * 3, true));
+  } else {
+    TRY(dev_alloc(e, &e->PA, frag_elems, true));
+    if (kernel == NGD_KERNEL_MFMA) TRY(dev_alloc(e, &e->QB, frag_elems, true));
+  }
+  if (cfg->pairwise_del) {
+    TRY(dev_alloc(e, &e->mask, g.n_ind * (uint64_t)g.n_words, true));
+    TRY(dev_alloc(e, &e->planes, 32ull * g.n_words, true));
+  }
+  TRY(dev_alloc(e, &e->d_ws, g.n_sites_pad + 4 * NGD_KG_TAIL, true));
+  TRY(dev_alloc(e, &e->d_sum, n_pairs, true));
+  TRY(dev_alloc(e, &e->d_cnt, n_pairs, true));
+
+  // ---- split over the site axis: slices -> slabs, reduced in fixed order ----
+  if (kernel == NGD_KERNEL_MFMA) {
+    uint64_t want = env_u64("NGD_MFMA_WG", 8192);
+    uint64_t ks = e->n_tiles ? (want + e->n_tiles - 1) / e->n_tiles : 8;
+    uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 64));
+    ks = std::min(ks, max_ks);
+    ks = env_u64("NGD_MFMA_KS", ks);
+    ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
+    e->n_ks = (uint32_t)ks;
+    e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
+    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+  } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
+    uint64_t want = env_u64("NGD_EM_WG", 4096);
+    uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
+    uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 256);
+    ks = std::min(ks, max_ks);
+    ks = std::max<uint64_t>(1, env_u64("NGD_EM_KS", ks));
+    e->n_ks = (uint32_t)ks;
+    e->per_slice = (g.n_sites + ks - 1) / ks;
+    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+  }
+  // upload staging: at most ~256 MiB of raw doubles
+  e->staging_sites = std::max<uint64_t>(1, std::min<uint64_t>(g.n_sites, (256ull << 20) / (g.n_ind * 24)));
+  TRY(dev_alloc(e, &e->staging, e->staging_sites * g.n_ind * 3, false));
+#undef TRY
+  if (hipStreamSynchronize(e->st) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: sync failed"));
+  *out = e;
+  return NGD_OK;
+}
+
+static int upload_common(ngd_engine *e, const double *p, int ind_major, uint64_t s0, uint64_t n) {
+  if (!e || !p) return fail(NGD_E_INVALID, "upload: null argument");
+  if (e->committed) return fail(NGD_E_INVALID, "upload: data set already committed");
+  if (s0 + n > e->g.n_sites || s0 + n < s0) return fail(NGD_E_INVALID, "upload: site range out of bounds");
+  HIPCHK(hipSetDevice(e->device));
+  const uint64_t n_ind = e->g.n_ind;
+  for (uint64_t done = 0; done < n;) {
+    const uint64_t c = std::min(e->staging_sites, n - done);
+    if (ind_major) {
+      // rows = individuals, each row = c sites x 24 B out of an n_sites-long row
+      HIPCHK(hipMemcpy2DAsync(e->staging, c * 24, p + (s0 + done) * 3, e->g.n_sites * 24, c * 24, n_ind,
+                              hipMemcpyHostToDevice, e->st));
+    } else {
+      HIPCHK(hipMemcpyAsync(e->staging, p + done * n_ind * 3, c * n_ind * 24, hipMemcpyHostToDevice, e->st));
+    }
+    ngd_launch_layout(e->st, e->g, e->staging, ind_major, s0 + done, c, e->sc, e->cfg.pairwise_del, e->PA,
+                      e->QB, e->PI, e->mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->st));  // staging buffer is reused by the next chunk
+    done += c;
+  }
+  return NGD_OK;
+}
+
+int ngd_upload_sites(ngd_engine *e, const double *p, uint64_t s0, uint64_t n) {
+  return upload_common(e, p, 0, s0, n);
+}
+
+int ngd_upload_ind_major(ngd_engine *e, const double *p) {
+  if (!e) return fail(NGD_E_INVALID, "upload: null engine");
+  return upload_common(e, p, 1, 0, e->g.n_sites);
+}
+
+int ngd_commit(ngd_engine *e) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_commit: null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->st));
+  if (e->staging) {  // upload is over: give the staging buffer back
+    HIPCHK(hipFree(e->staging));
+    e->dev_bytes -= e->staging_sites * e->g.n_ind * 24;
+    e->staging = nullptr;
+  }
+  e->committed = true;
+  return NGD_OK;
+}
+
+int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_synth_fill: null engine");
+  if (e->committed) return fail(NGD_E_INVALID, "ngd_synth_fill: data set already committed");
+  HIPCHK(hipSetDevice(e->device));
+  ngd_launch_synth(e->st, e->g, seed, miss_frac, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask);
+  HIPCHK(hipGetLastError());
+  return ngd_commit(e);
+}
+
+static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
+                    double *d_sum, unsigned long long *d_cnt) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
+  if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
+  HIPCHK(hipSetDevice(e->device));
+  const ngd_geom &g = e->g;
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
+  uint64_t n_eff = g.n_sites;
+  const uint32_t *ws = nullptr;
+  uint32_t n_planes = 0;
+
+  HIPCHK(hipEventRecord(e->ev[0], e->st));
+  if (block_map) {
+    if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
+    if (n_blocks > g.n_sites / block_size)
+      return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
+    n_eff = n_blocks * block_size;
+    std::vector<uint32_t> mult(n_blocks, 0);
+    uint32_t mx = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+      if (block_map[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
+      mx = std::max(mx, ++mult[block_map[b]]);
+    }
+    while (n_planes < 32 && (mx >> n_planes)) n_planes++;
+    if (n_blocks > e->cap_blocks) {
+      if (e->d_block_map) { hipFree(e->d_block_map); e->dev_bytes -= e->cap_blocks * 8; }
+      if (e->d_mult) { hipFree(e->d_mult); e->dev_bytes -= e->cap_blocks * 4; }
+      e->d_block_map = nullptr; e->d_mult = nullptr; e->cap_blocks = 0;
+      int rc = dev_alloc(e, &e->d_block_map, n_blocks, false);
+      if (rc) return rc;
+      rc = dev_alloc(e, &e->d_mult, n_blocks, false);
+      if (rc) return rc;
+      e->cap_blocks = n_blocks;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_block_map, block_map, n_blocks * 8, hipMemcpyHostToDevice, e->st));
+    ngd_launch_weights(e->st, e->d_block_map, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws);
+    ws = e->d_ws;
+  }
+
+  HIPCHK(hipMemsetAsync(d_sum, 0, n_pairs * sizeof(double), e->st));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, n_pairs * sizeof(unsigned long long), e->st));
+
+  HIPCHK(hipEventRecord(e->ev[1], e->st));
+  switch (e->kernel) {
+    case NGD_KERNEL_STREAM:
+      ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
+                              e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
+      break;
+    case NGD_KERNEL_MFMA:
+      ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
+                            g.n_kg, e->slab);
+      break;
+    default:
+      ngd_launch_accum_em(e->st, g, e->PA, ws, n_eff, e->sc, e->cfg.pairwise_del,
+                          e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, e->n_ks,
+                          e->per_slice, e->slab);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[2], e->st));
+  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
+  HIPCHK(hipEventRecord(e->ev[3], e->st));
+  if (e->cfg.pairwise_del) {
+    if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
+    ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles16, e->n_tiles16, d_cnt);
+  } else {
+    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, n_eff, d_cnt);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[4], e->st));
+  HIPCHK(hipStreamSynchronize(e->st));
+
+  float ms = 0;
+  ngd_timing &t = e->timing;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[4])); t.ms_total = ms;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); t.ms_accum = ms;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); t.ms_reduce = ms;
+  HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); t.ms_count = ms;
+  t.pair_sites = e->n_owned_pairs * n_eff;
+  t.launches = 1;
+  return NGD_OK;
+}
+
+int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
+                   void *d_sum, void *d_cnt) {
+  if (!d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_device: null output");
+  return run_impl(e, block_map, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+}
+
+int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size, double *sum,
+            uint64_t *cnt) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
+  int rc = run_impl(e, block_map, n_blocks, block_size, e->d_sum, e->d_cnt);
+  if (rc) return rc;
+  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
+  if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+  if (cnt) HIPCHK(hipMemcpy(cnt, e->d_cnt, n_pairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return NGD_OK;
+}
+
+int ngd_last_timing(const ngd_engine *e, ngd_timing *t) {
+  if (!e || !t) return fail(NGD_E_INVALID, "ngd_last_timing: null argument");
+  *t = e->timing;
+  return NGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// layout.hip -- turns the caller's prepared GL array into the device-resident
+// operand images (see ngd_internal.h for the fragment-major layout), derives
+// the missing-site masks (reference gen_func.cpp:862-868) and, for bootstrap,
+// expands a block map (reference ngsDist.cpp:416-437) into per-site
+// multiplicities instead of moving any data.
+#include "ngd_internal.h"
+
+namespace {
+
+// One (individual, site): write every image that is allocated.
+__device__ __forceinline__ void emit(const ngd_geom &g, const ngd_score &sc, int pairwise_del,
+                                     uint64_t s, uint32_t i, double p0, double p1, double p2,
+                                     double *PA, double *QB, double *PI, unsigned long long *mask) {
+  if (PI) {  // individual-major copy for the streaming kernel (unmasked, as gen_dist reads it)
+    double *d = PI + (i * g.n_sites_pad + s) * 3;
+    d[0] = p0; d[1] = p1; d[2] = p2;
+  }
+  bool miss = ngd_miss(p0, p1, p2);
+  if (mask && !miss) atomicOr(&mask[(uint64_t)i * g.n_words + (s >> 6)], 1ull << (s & 63));
+  if (pairwise_del && miss) { p0 = 0; p1 = 0; p2 = 0; }  // a skipped site contributes nothing
+  uint64_t k = 3 * s;
+  if (PA) {
+    PA[ngd_frag_off(k, i, g.n_ig)] = p0;
+    PA[ngd_frag_off(k + 1, i, g.n_ig)] = p1;
+    PA[ngd_frag_off(k + 2, i, g.n_ig)] = p2;
+  }
+  if (QB) {  // q[g1] = sum_g2 score[g1][g2] * p[g2]
+    for (int a = 0; a < 3; a++) {
+      double q = sc.v[3 * a] * p0;
+      q = q + sc.v[3 * a + 1] * p1;
+      q = q + sc.v[3 * a + 2] * p2;
+      QB[ngd_frag_off(k + a, i, g.n_ig)] = q;
+    }
+  }
+}
+
+__global__ void k_layout(ngd_geom g, const double *__restrict__ raw, int raw_ind_major, uint64_t s0,
+                         uint64_t n_chunk, ngd_score sc, int pairwise_del, double *PA, double *QB,
+                         double *PI, unsigned long long *mask) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_chunk * g.n_ind) return;
+  uint64_t sl = e / g.n_ind;
+  uint32_t i = (uint32_t)(e - sl * g.n_ind);
+  const double *src = raw_ind_major ? raw + ((uint64_t)i * n_chunk + sl) * 3 : raw + e * 3;
+  emit(g, sc, pairwise_del, s0 + sl, i, src[0], src[1], src[2], PA, QB, PI, mask);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// Counter-based synthetic data, bit-identical to oracle ngo_synth_one().
+__global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, ngd_score sc, int pairwise_del,
+                        double *PA, double *QB, double *PI, unsigned long long *mask) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.n_sites * g.n_ind) return;
+  uint64_t s = e / g.n_ind;
+  uint32_t i = (uint32_t)(e - s * g.n_ind);
+  uint64_t base = seed * 0x9E3779B97F4A7C15ull;
+  double x[3];
+  for (int c = 0; c < 3; c++) {
+    uint64_t z = mix64(base + (e * 3 + (uint64_t)c));
+    double u = ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    x[c] = (u * u) * u;
+  }
+  double t = (x[0] + x[1]) + x[2];
+  double p0 = x[0] / t, p1 = x[1] / t, p2 = x[2] / t;
+  if (miss_frac > 0) {
+    uint64_t z = mix64(base ^ (0xD1B54A32D192ED03ull + e));
+    double u = ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    if (u < miss_frac) p0 = p1 = p2 = (double)1 / 3;
+  }
+  emit(g, sc, pairwise_del, s, i, p0, p1, p2, PA, QB, PI, mask);
+}
+
+__global__ void k_mult(const uint64_t *__restrict__ block_map, uint64_t n_blocks, uint32_t *mult) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_blocks) atomicAdd(&mult[block_map[b]], 1u);  // integer adds: order-independent
+}
+
+__global__ void k_expand(const uint32_t *__restrict__ mult, uint64_t n_eff, uint64_t block_size,
+                         uint64_t n_sites, uint32_t *ws) {
+  uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sites) return;
+  ws[s] = s < n_eff ? mult[s / block_size] : 0u;
+}
+
+// bit-planes of the per-site multiplicity, for weighted valid-site counts
+__global__ void k_planes(const uint32_t *__restrict__ ws, uint64_t n_sites, uint32_t n_words,
+                         uint32_t n_planes, unsigned long long *planes) {
+  uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  for (uint32_t b = 0; b < n_planes; b++) {
+    unsigned long long bits = 0;
+    for (int t = 0; t < 64; t++) {
+      uint64_t s = (uint64_t)w * 64 + t;
+      if (s < n_sites && ((ws[s] >> b) & 1u)) bits |= 1ull << t;
+    }
+    planes[(uint64_t)b * n_words + w] = bits;
+  }
+}
+
+}  // namespace
+
+void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
+                       uint64_t s0, uint64_t n_chunk, const ngd_score &score, int pairwise_del,
+                       double *PA, double *QB, double *PI, unsigned long long *mask) {
+  uint64_t n = n_chunk * g.n_ind;
+  if (!n) return;
+  hipLaunchKernelGGL(k_layout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, raw,
+                     raw_ind_major, s0, n_chunk, score, pairwise_del, PA, QB, PI, mask);
+}
+
+void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,
+                      const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
+                      unsigned long long *mask) {
+  uint64_t n = g.n_sites * g.n_ind;
+  hipLaunchKernelGGL(k_synth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, seed,
+                     miss_frac, score, pairwise_del, PA, QB, PI, mask);
+}
+
+void ngd_launch_weights(hipStream_t st, const uint64_t *d_block_map, uint64_t n_blocks,
+                        uint64_t block_size, uint64_t n_sites, uint32_t *d_mult, uint32_t *d_ws) {
+  hipMemsetAsync(d_mult, 0, n_blocks * sizeof(uint32_t), st);
+  hipLaunchKernelGGL(k_mult, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_block_map,
+                     n_blocks, d_mult);
+  hipLaunchKernelGGL(k_expand, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, d_mult,
+                     n_blocks * block_size, block_size, n_sites, d_ws);
+}
+
+void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
+                       uint32_t n_planes, unsigned long long *d_planes) {
+  hipLaunchKernelGGL(k_planes, dim3((n_words + 255) / 256), dim3(256), 0, st, d_ws, n_sites, n_words,
+                     n_planes, d_planes);
+}

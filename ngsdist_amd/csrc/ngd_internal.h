@@ -1,0 +1,96 @@
+// Internal declarations shared by the engine and its kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngsdist_amd.h"
+
+#define NGD_TILE 128     // pair tile edge owned by one workgroup of the MFMA kernel
+#define NGD_IG 16        // individuals per fragment group (one MFMA operand edge)
+#define NGD_IG_PER_TILE (NGD_TILE / NGD_IG)
+#define NGD_KG_TAIL 8    // zeroed k-groups appended to the operand images (pipeline run-ahead)
+
+typedef double ngd_d4 __attribute__((ext_vector_type(4)));
+
+struct ngd_score {
+  double v[9];
+};
+
+// Geometry of the resident data set.
+//
+// Fragment-major operand layout ("PA", and "QB" = score-weighted copy):
+//   the contraction index is k = 3*s + g  (site s, genotype g);
+//   element (i, k) lives at  ((k/4)*n_ig + i/16)*64 + (k%4)*16 + i%16.
+// One 64-double group (512 B) is exactly the per-lane operand image of
+// v_mfma_f64_16x16x4_f64 (lane l <-> individual l&15, k-offset l>>4), so a
+// wavefront fetches an operand with one fully coalesced 512-B load and 16
+// consecutive individuals of one (site, genotype) are 128 contiguous bytes.
+struct ngd_geom {
+  uint64_t n_ind;
+  uint64_t n_sites;
+  uint64_t n_sites_pad;  // multiple of 16 -> n_kg multiple of 12
+  uint64_t n_kg;         // k groups of 4 = 3*n_sites_pad/4
+  uint32_t n_ig;         // individual groups of 16, padded to a multiple of 8
+  uint32_t n_t;          // 128-individual tiles per edge
+  uint32_t n_pad;        // n_t * 128
+  uint32_t n_words;      // 64-site mask words per individual
+};
+
+__host__ __device__ inline uint64_t ngd_frag_off(uint64_t k, uint32_t i, uint32_t n_ig) {
+  return ((k >> 2) * n_ig + (i >> 4)) * 64 + (k & 3) * 16 + (i & 15);
+}
+
+// row-major upper-triangle pair index, ngsDist.cpp:244-245
+__host__ __device__ inline uint64_t ngd_pair_idx(uint64_t n, uint64_t i, uint64_t j) {
+  return i * (2 * n - i - 1) / 2 + (j - i - 1);
+}
+
+// miss_data(), reference gen_func.cpp:862-868 (EPSILON = 1e-5, gen_func.hpp:16)
+__host__ __device__ inline bool ngd_miss(double p0, double p1, double p2) {
+  double a = p0 - p1, b = p1 - p2;
+  a = (a >= 0 ? a : -a);
+  b = (b >= 0 ? b : -b);
+  return a < 1e-5 && b < 1e-5;
+}
+
+struct ngd_tile {
+  uint16_t ti, tj;  // tile coordinates (units depend on the list: 128 or 16 individuals)
+};
+
+// ---- kernel launchers (each in its own .hip file) -------------------------
+// layout.hip
+void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
+                       uint64_t s0, uint64_t n_sites_chunk, const ngd_score &score, int pairwise_del,
+                       double *PA, double *QB, double *PI, unsigned long long *mask);
+void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,
+                      const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
+                      unsigned long long *mask);
+void ngd_launch_weights(hipStream_t st, const uint64_t *d_block_map, uint64_t n_blocks,
+                        uint64_t block_size, uint64_t n_sites, uint32_t *d_mult, uint32_t *d_ws);
+void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
+                       uint32_t n_planes, unsigned long long *d_planes);
+
+// accum_stream.hip : one wavefront per pair
+void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI, const uint32_t *d_ws,
+                             uint64_t n_sites_eff, const ngd_score &score, int pairwise_del,
+                             const uint64_t *d_pairs, uint64_t n_owned, double *d_sum);
+
+// accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
+void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
+                           const uint32_t *d_ws, const ngd_tile *d_tiles, uint32_t n_tiles,
+                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
+
+// accum_em.hip : per-site EM, one thread per pair of a 16x16 tile
+void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
+                         uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,
+                         const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
+                         uint64_t sites_per_slice, double *slab);
+
+// reduce.hip : deterministic slab reduction + valid-site counting
+void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
+                       const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
+void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
+                      const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles16,
+                      uint32_t n_tiles16, unsigned long long *d_cnt);
+void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_tiles, uint32_t n_tiles,
+                         unsigned long long value, unsigned long long *d_cnt);

@@ -1,0 +1,166 @@
+"""Host-side handle on the MI355X engine (ctypes over include/ngsdist_amd.h).
+
+The reference is a compiled C++ program, so the product's host is the C++
+driver under ngsdist_amd/csrc/host/ (same command line as ngsDist); this module
+is the thin Python door the tests and bench.py use.  Names follow the
+reference: gen_dist / evol_model / pairwise_del / indep_geno / tot_sites /
+boot_block_size (ngsDist.hpp:11-44).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4}
+
+# parse_args.cpp:25-27
+DEFAULT_SCORE = (0.0, 0.5, 1.0, 0.5, 0.0, 0.5, 1.0, 0.5, 0.0)
+
+
+class NgdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ngsdist_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise NgdError(rc, _lib.load().ngd_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return _lib.load().ngd_device_count()
+
+
+def n_pairs(n_ind):
+    return n_ind * (n_ind - 1) // 2
+
+
+def score_matrix(avg_nuc_dist=False):
+    s = list(DEFAULT_SCORE)
+    if avg_nuc_dist:  # --avg_nuc_dist, parse_args.cpp:134-137
+        s[4] = 0.5
+    return s
+
+
+class Engine:
+    """One resident data set on one GPU; `run()` = one replicate's worth of
+    gen_dist() over every pair this engine's shard owns."""
+
+    def __init__(self, n_ind, n_sites, score=None, pairwise_del=False, indep_geno=True, kernel="auto",
+                 device=-1, shard_rank=0, shard_world=1):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        cfg = _lib.NgdConfig()
+        cfg.n_ind, cfg.n_sites = int(n_ind), int(n_sites)
+        sc = DEFAULT_SCORE if score is None else [float(x) for x in np.asarray(score).reshape(9)]
+        for k in range(9):
+            cfg.score[k] = sc[k]
+        cfg.pairwise_del, cfg.indep_geno = int(bool(pairwise_del)), int(bool(indep_geno))
+        cfg.device, cfg.kernel = int(device), KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
+        self.n_ind, self.n_sites = int(n_ind), int(n_sites)
+        self.n_pairs = n_pairs(self.n_ind)
+        _check(self._L.ngd_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.ngd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- input --------------------------------------------------------------
+    def upload_ind_major(self, p):
+        """p[n_ind][n_sites][3]: in_geno_lkl as gen_dist reads it (normal space)."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert p.shape == (self.n_ind, self.n_sites, 3), p.shape
+        _check(self._L.ngd_upload_ind_major(self._h, p.ctypes.data_as(C.POINTER(C.c_double))))
+        return self
+
+    def upload_sites(self, p, s0=0):
+        """p[n][n_ind][3]: a run of sites in the binary file's order."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        assert p.ndim == 3 and p.shape[1:] == (self.n_ind, 3), p.shape
+        _check(self._L.ngd_upload_sites(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), int(s0), p.shape[0]))
+        return self
+
+    def commit(self):
+        _check(self._L.ngd_commit(self._h))
+        return self
+
+    def synth_fill(self, seed, miss_frac=0.0):
+        _check(self._L.ngd_synth_fill(self._h, int(seed), float(miss_frac)))
+        return self
+
+    # -- the hot path ---------------------------------------------------------
+    def _map_args(self, block_map, block_size):
+        if block_map is None:
+            return None, 0, 0, None
+        bm = np.ascontiguousarray(block_map, dtype=np.uint64)
+        return bm.ctypes.data_as(C.POINTER(C.c_uint64)), bm.size, int(block_size), bm
+
+    def run(self, block_map=None, block_size=1):
+        """-> (sum float64[n_pairs], cnt uint64[n_pairs]) in the reference's pair order."""
+        ptr, nb, bs, keep = self._map_args(block_map, block_size)
+        s = np.empty(self.n_pairs, dtype=np.float64)
+        c = np.empty(self.n_pairs, dtype=np.uint64)
+        _check(self._L.ngd_run(self._h, ptr, nb, bs, s.ctypes.data_as(C.POINTER(C.c_double)),
+                               c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return s, c
+
+    def run_device(self, d_sum_ptr, d_cnt_ptr, block_map=None, block_size=1):
+        """Results written to caller-owned device buffers (raw addresses)."""
+        ptr, nb, bs, keep = self._map_args(block_map, block_size)
+        _check(self._L.ngd_run_device(self._h, ptr, nb, bs, C.c_void_p(d_sum_ptr), C.c_void_p(d_cnt_ptr)))
+
+    def timing(self):
+        t = _lib.NgdTiming()
+        _check(self._L.ngd_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def device_bytes(self):
+        return int(self._L.ngd_device_bytes(self._h))
+
+
+def finish(sum_, cnt, tot_sites=0, evol_model=1):
+    """Tail of gen_dist(), ngsDist.cpp:372-401, on the host's libm."""
+    L = _lib.load()
+    s = np.ascontiguousarray(sum_, dtype=np.float64)
+    c = np.ascontiguousarray(cnt, dtype=np.uint64)
+    out = np.empty_like(s)
+    _check(L.ngd_finish(s.ctypes.data_as(C.POINTER(C.c_double)), c.ctypes.data_as(C.POINTER(C.c_uint64)),
+                        s.size, int(tot_sites), int(evol_model), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+class Taus:
+    """gsl_rng_taus as the reference seeds and draws it (ngsDist.cpp:179-180, :421-423)."""
+
+    def __init__(self, seed):
+        self._L = _lib.load()
+        self._st = (C.c_uint32 * 3)()
+        self._L.ngd_taus_seed(self._st, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+    def get(self):
+        return int(self._L.ngd_taus_get(self._st))
+
+    def uniform(self):
+        return float(self._L.ngd_taus_uniform(self._st))
+
+    def block_map(self, n_blocks):
+        m = np.empty(int(n_blocks), dtype=np.uint64)
+        self._L.ngd_boot_block_map(self._st, int(n_blocks), m.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return m

@@ -1,0 +1,212 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle.
+
+Bars (BASELINE.json north_star): bit-exact for called-genotype ("integer")
+distances; <= 1e-9 relative for GL / EM floating-point distances.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9  # north_star tolerance for GL/EM floating point
+
+SP = os.path.join(os.path.dirname(__file__), "golden", "survey_probe")
+
+
+def N():
+    import ngsdist_amd
+    return ngsdist_amd
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    den = np.where(b == 0, 1.0, np.abs(b))
+    return float(np.max(np.abs(a - b) / den)) if a.size else 0.0
+
+
+def gpu_pairs(p, kernel, pairwise_del=False, indep_geno=True, score=None, block_map=None, block_size=1,
+              ind_major=True):
+    n_ind, n_sites, _ = p.shape
+    with N().Engine(n_ind, n_sites, score=score, pairwise_del=pairwise_del, indep_geno=indep_geno,
+                    kernel=kernel) as e:
+        if ind_major:
+            e.upload_ind_major(p)
+        else:  # site-major in two uneven chunks, like a host streaming the binary file
+            sm = np.ascontiguousarray(p.transpose(1, 0, 2))
+            cut = max(1, n_sites // 3)
+            e.upload_sites(sm[:cut], 0)
+            if cut < n_sites:
+                e.upload_sites(sm[cut:], cut)
+        e.commit()
+        return e.run(block_map, block_size)
+
+
+INDEP_KERNELS = ["stream", "mfma"]
+EM_KERNELS = ["em_faithful", "em_fast"]
+
+
+@pytest.mark.parametrize("kernel", INDEP_KERNELS)
+@pytest.mark.parametrize("n_ind,n_sites", [(2, 1), (3, 5), (6, 200), (17, 333), (24, 10000), (130, 1000), (257, 515)])
+def test_indep_gl(kernel, n_ind, n_sites):
+    p = O.synth_indmajor(3, n_ind, n_sites)
+    s, c = gpu_pairs(p, kernel)
+    so, co = O.all_pairs(p, n_threads=8)
+    assert np.array_equal(c, co)
+    assert rel_err(s, so) < RTOL
+
+
+@pytest.mark.parametrize("kernel", INDEP_KERNELS)
+def test_indep_pairwise_del_and_upload_by_sites(kernel):
+    p = O.synth_indmajor(5, 40, 3000, miss_frac=0.2)
+    s, c = gpu_pairs(p, kernel, pairwise_del=True, ind_major=False)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    assert np.array_equal(c, co)
+    assert c.min() < 3000
+    assert rel_err(s, so) < RTOL
+
+
+@pytest.mark.parametrize("kernel", INDEP_KERNELS)
+def test_called_genotypes_bit_exact(kernel):
+    """--call_geno / genotype input: every term is a multiple of 0.5 -> any order is exact."""
+    rng = np.random.default_rng(1)
+    n_ind, n_sites = 24, 10000  # examples/test.sh testA shape
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    for avg in (False, True):
+        sc = O.score_matrix(avg)
+        s, c = gpu_pairs(p, kernel, score=sc)
+        so, co = O.all_pairs(p, score=sc, n_threads=8)
+        assert np.array_equal(s, so) and np.array_equal(c, co)
+        for model in (0, 1, 2):
+            with np.errstate(all="ignore"):
+                d = N().finish(s, c, 0, model)
+                do = O.finish(so, co, 0, model)
+            assert np.array_equal(d, do, equal_nan=True)  # bit-exact distances
+
+
+@pytest.mark.parametrize("kernel", INDEP_KERNELS)
+def test_golden_t_gl(kernel):
+    raw = np.fromfile(os.path.join(SP, "t_gl.bin"), dtype=np.float64)
+    p = O.prep_binary(raw, 6, 200)
+    s, c = gpu_pairs(p, kernel)
+    d = N().finish(s, c, 0, 0)
+    txt, _ = O.format_matrix(d, O.default_labels(6))
+    assert txt == open(os.path.join(SP, "t_gl_I0.dist")).read()
+    pc = O.prep_binary(raw, 6, 200, call_geno=True)
+    s, c = gpu_pairs(pc, kernel)
+    txt, _ = O.format_matrix(N().finish(s, c, 0, 0), O.default_labels(6))
+    assert txt == open(os.path.join(SP, "t_gl_CG.dist")).read()
+
+
+@pytest.mark.parametrize("kernel", EM_KERNELS)
+def test_golden_em(kernel):
+    raw = np.fromfile(os.path.join(SP, "t_gl.bin"), dtype=np.float64)
+    p = O.prep_binary(raw, 6, 200)
+    s, c = gpu_pairs(p, kernel, indep_geno=False)
+    txt, _ = O.format_matrix(N().finish(s, c, 0, 2), O.default_labels(6))
+    assert txt == open(os.path.join(SP, "t_gl_EM2.dist")).read()
+
+
+@pytest.mark.parametrize("kernel", EM_KERNELS)
+@pytest.mark.parametrize("n_ind,n_sites,miss", [(2, 1, 0.0), (6, 200, 0.0), (33, 700, 0.1), (20, 5000, 0.0)])
+def test_em(kernel, n_ind, n_sites, miss):
+    p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=miss)
+    for pd in (False, True):
+        s, c = gpu_pairs(p, kernel, pairwise_del=pd, indep_geno=False)
+        so, co = O.all_pairs(p, pairwise_del=pd, indep_geno=False, n_threads=8)
+        assert np.array_equal(c, co)
+        assert rel_err(s, so) < RTOL
+
+
+@pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
+@pytest.mark.parametrize("block_size", [1, 7, 64])
+def test_bootstrap_replicates(kernel, block_size):
+    n_ind, n_sites = 12, 1000
+    indep = kernel in INDEP_KERNELS
+    p = O.synth_indmajor(21, n_ind, n_sites, miss_frac=0.1)
+    rng_o, rng_g = O.Taus(12345), N().Taus(12345)
+    n_eff = n_sites - n_sites % block_size
+    with N().Engine(n_ind, n_sites, pairwise_del=True, indep_geno=indep, kernel=kernel) as e:
+        e.upload_ind_major(p).commit()
+        for rep in range(3):
+            bm_o = rng_o.block_map(n_eff // block_size)
+            bm_g = rng_g.block_map(n_eff // block_size)
+            assert np.array_equal(bm_o, bm_g)
+            s, c = e.run(bm_g, block_size)
+            so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep,
+                                 site_src=O.boot_site_src(bm_o, block_size), n_sites=n_eff, n_threads=8)
+            assert np.array_equal(c, co)
+            assert rel_err(s, so) < RTOL
+        # and the full data set again afterwards: bootstrap never moved data
+        s, c = e.run()
+        so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, n_threads=8)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
+def test_heavy_multiplicity_counts():
+    """all blocks map to block 0 -> multiplicity n_blocks on a few sites (bit-plane path)."""
+    n_ind, n_sites, B = 5, 640, 2
+    p = O.synth_indmajor(4, n_ind, n_sites, miss_frac=0.3)
+    bm = np.zeros(n_sites // B, dtype=np.uint64)
+    s, c = gpu_pairs(p, "mfma", pairwise_del=True, block_map=bm, block_size=B)
+    so, co = O.all_pairs(p, pairwise_del=True, site_src=O.boot_site_src(bm, B), n_threads=4)
+    assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
+def test_synth_fill_matches_oracle_generator():
+    n_ind, n_sites = 37, 901
+    p = O.synth_indmajor(77, n_ind, n_sites, miss_frac=0.05)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    for kernel in INDEP_KERNELS:
+        with N().Engine(n_ind, n_sites, pairwise_del=True, kernel=kernel) as e:
+            s, c = e.synth_fill(77, 0.05).run()
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "stream", "em_fast"])
+def test_shards_partition_the_pairs(kernel):
+    n_ind, n_sites, world = 300, 256, 3
+    p = O.synth_indmajor(8, n_ind, n_sites)
+    indep = kernel != "em_fast"
+    tot_s = np.zeros(N().n_pairs(n_ind))
+    tot_c = np.zeros(N().n_pairs(n_ind), dtype=np.uint64)
+    owned = np.zeros(N().n_pairs(n_ind), dtype=np.int32)
+    for r in range(world):
+        with N().Engine(n_ind, n_sites, indep_geno=indep, kernel=kernel, shard_rank=r, shard_world=world) as e:
+            s, c = e.upload_ind_major(p).commit().run()
+        owned += (c > 0)
+        tot_s += s
+        tot_c += c
+    assert np.all(owned == 1)  # disjoint cover -> summing shards == gathering them
+    so, co = O.all_pairs(p, indep_geno=indep, n_threads=8)
+    assert np.array_equal(tot_c, co) and rel_err(tot_s, so) < RTOL
+
+
+def test_deterministic_run_to_run():
+    p = O.synth_indmajor(2, 150, 4096)
+    with N().Engine(150, 4096, kernel="mfma") as e:
+        e.upload_ind_major(p).commit()
+        a = e.run()[0]
+        b = e.run()[0]
+    assert np.array_equal(a, b)
+
+
+def test_errors_are_codes_not_exits():
+    n = N()
+    with pytest.raises(n.NgdError):
+        n.Engine(1, 10)
+    with pytest.raises(n.NgdError):
+        n.Engine(4, 10, indep_geno=True, kernel="em_fast")
+    with n.Engine(4, 10) as e:
+        with pytest.raises(n.NgdError):
+            e.run()  # not committed
+        e.upload_ind_major(np.full((4, 10, 3), 1 / 3)).commit()
+        with pytest.raises(n.NgdError):
+            e.run(np.array([0, 11], dtype=np.uint64), 1)  # map entry out of range
+    with pytest.raises(n.NgdError):
+        n.finish(np.zeros(1), np.ones(1, dtype=np.uint64), 0, 3)  # K80..TN93: reference error()s
