@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- pair-distances/s of the gen_dist() hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--kernel ...]
+
+One "step" = one replicate of the hot path over the whole resident data set:
+accumulation kernel(s) -> deterministic slab reduction -> (N>1: RCCL reduce of
+the disjoint shards to rank 0) -> copy to host -> /cnt and evolutionary-model
+transform with the host's libm (the tail of gen_dist, ngsDist.cpp:372-401).
+Inputs are synthetic (counter-based generator), generated ON the GPU
+before the timed region, replicated per rank; pair tiles are dealt over ranks
+(strong scaling: the matrix is fixed as N grows).
+
+Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
+`roofline` for the dominant kernel from HIP-event timings taken inside this run,
+and `cpu_baseline` = the CPU oracle (a port of the reference algorithm, NOT the
+product path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic cost per pair-site
+BYTES_PER_PAIR_SITE = 48.0  # stream model: two 3-double GL vectors per pair-site
+FLOPS_PER_PAIR_SITE = 6.0   # tiled model: 3 FP64 FMA per pair-site (P . Q^T, K = 3*n_sites)
+PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (SURVEY 8d hardware constants)
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+
+WORKLOADS = {
+    # BASELINE.json configs[1..4]
+    "cfg2": dict(n_ind=200, n_sites=100_000, indep=True, evol_model=0, seed=2, n_boot=0, block=1),
+    "cfg3": dict(n_ind=1000, n_sites=1_000_000, indep=True, evol_model=1, seed=3, n_boot=0, block=1),
+    "cfg4": dict(n_ind=1000, n_sites=1_000_000, indep=False, evol_model=2, seed=3, n_boot=0, block=1),
+    "cfg5": dict(n_ind=500, n_sites=500_000, indep=True, evol_model=1, seed=5, n_boot=64, block=1000),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_fast", "em_faithful"])
+    ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
+    ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: one HIP runtime in the process (see ngsdist_amd/_lib.py)
+    import torch.distributed as dist
+
+    import ngsdist_amd as N
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py: --gpus %d needs a torch.distributed.run launch" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W = dict(WORKLOADS[args.workload])
+    if args.n_sites:
+        W["n_sites"] = args.n_sites
+    n_ind, n_sites = W["n_ind"], W["n_sites"]
+    n_pairs = N.n_pairs(n_ind)
+    kernel = args.kernel
+    if kernel == "auto":
+        kernel = "mfma" if W["indep"] else "em_fast"
+
+    eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank,
+                   shard_rank=rank, shard_world=world)
+    eng.synth_fill(W["seed"], 0.0)
+
+    d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+    h_sum = torch.empty(n_pairs, dtype=torch.float64).pin_memory()
+    h_cnt = torch.empty(n_pairs, dtype=torch.int64).pin_memory()
+
+    # bootstrap workloads: replicate r>0 draws its block map from the reference's taus stream
+    n_mat = W["n_boot"] + 1
+    n_eff = n_sites - n_sites % W["block"]
+    rng = N.Taus(12345)
+    maps = [None] + [rng.block_map(n_eff // W["block"]) for _ in range(W["n_boot"])]
+
+    acc_ms, red_ms, tot_ms, pair_sites = [], [], [], []
+    last = {}
+
+    def step(record):
+        for rep in range(n_mat):
+            eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rep], W["block"])
+            if record:
+                t = eng.timing()
+                acc_ms.append(t["ms_accum"]); red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
+                pair_sites.append(t["pair_sites"])
+            if world > 1:  # disjoint shards: SUM == gather (x + 0 is exact)
+                dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+                dist.reduce(d_cnt, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                h_sum.copy_(d_sum, non_blocking=True)
+                h_cnt.copy_(d_cnt, non_blocking=True)
+                torch.cuda.synchronize()
+                with np.errstate(all="ignore"):
+                    last["dist"] = N.finish(h_sum.numpy(), h_cnt.numpy().view(np.uint64), 0, W["evol_model"])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # per-rank accumulation-kernel time: report the slowest rank's mean
+        am = torch.tensor([float(np.mean(acc_ms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(am, op=dist.ReduceOp.MAX)
+        acc_mean_ms = float(am.item())
+        ps = torch.tensor([float(np.mean(pair_sites))], dtype=torch.float64, device=dev)
+        dist.all_reduce(ps, op=dist.ReduceOp.SUM)
+        pair_sites_per_launch_all = float(ps.item())
+    else:
+        acc_mean_ms = float(np.mean(acc_ms))
+        pair_sites_per_launch_all = float(np.mean(pair_sites))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt * 1e3 / args.steps
+    value = n_pairs * n_mat * args.steps / dt
+    # spot check against the CPU oracle: a few pairs over ALL sites of the last matrix computed
+    spot = None
+    cpu = None
+    try:
+        from oracle import oracle as O
+        if W["indep"] and maps[-1] is None:
+            idx = [0, 1, n_ind // 2, n_ind - 1]
+            sub = np.concatenate([O.synth_indmajor(W["seed"], n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+            so, co = O.all_pairs(sub, indep_geno=True, n_threads=4)
+            with np.errstate(all="ignore"):
+                do = O.finish(so, co, 0, W["evol_model"])
+            k = 0
+            worst = 0.0
+            for a in range(len(idx)):
+                for b in range(a + 1, len(idx)):
+                    g = last["dist"][N.n_pairs(n_ind) - N.n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
+                    worst = max(worst, abs(g - do[k]) / abs(do[k]))
+                    k += 1
+            spot = {"pairs": k, "sites": n_sites, "max_rel_err_vs_oracle": worst}
+        if not args.no_cpu:
+            cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
+            rate_guess = (1.0e8 if W["indep"] else 2.0e5) * cores  # pair-sites/s, from DESIGN.md
+            cs = args.cpu_sites or int(max(64, min(n_sites, 15.0 * rate_guess / n_pairs)))
+            pc = O.synth_indmajor(W["seed"], n_ind, cs)
+            tc = time.perf_counter()
+            O.all_pairs(pc, indep_geno=W["indep"], n_threads=cores)
+            tc = time.perf_counter() - tc
+            cpu_ps = n_pairs * cs / tc
+            cpu = {"value": cpu_ps / n_sites, "unit": "pair-distances/s", "cores": cores, "kind": "port",
+                   "pair_sites_per_s": cpu_ps, "seconds": tc,
+                   "sample": "first %d of %d sites, all %d pairs, same generator/seed; rate scaled linearly "
+                             "in n_sites to one full matrix" % (cs, n_sites, n_pairs)}
+    except Exception as exc:  # the oracle is a checker; never let it take the bench line down
+        cpu = {"error": repr(exc)}
+
+    t_acc = acc_mean_ms * 1e-3
+    if W["indep"]:
+        flops = FLOPS_PER_PAIR_SITE * pair_sites_per_launch_all / world  # per launch of ONE rank's kernel
+        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": flops / t_acc / 1e12,
+                "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": flops / t_acc / 1e12 / PEAK_FP64_TFLOPS,
+                "traffic": None, "ms_per_launch": acc_mean_ms,
+                "algorithmic": "%.0f FP64 flop per pair-site x %.4g pair-sites per launch"
+                               % (FLOPS_PER_PAIR_SITE, pair_sites_per_launch_all / world)}
+        sb = BYTES_PER_PAIR_SITE * pair_sites_per_launch_all / world / t_acc / 1e9
+        roof["stream_model"] = {"bound": "hbm", "achieved": sb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": sb / PEAK_HBM_GBS,
+                                "algorithmic": "48 B per pair-site (north_star's one-wavefront-per-pair model)"}
+        if kernel == "stream":
+            roof = dict(roof["stream_model"], kernel="k_accum_stream", traffic=None, ms_per_launch=acc_mean_ms)
+    else:
+        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
+                "pair_sites_per_s": pair_sites_per_launch_all / world / t_acc,
+                "algorithmic": "FP64 VALU bound; flops are data dependent (EM iterations per site)"}
+
+    out = {
+        "metric": "pair-distances/sec", "value": value, "unit": "pair-distances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: n_ind=%d n_sites=%d %s evol_model=%d n_boot_rep=%d boot_block_size=%d"
+                               % (args.workload, n_ind, n_sites, "--indep_geno" if W["indep"] else "EM",
+                                  W["evol_model"], W["n_boot"], W["block"]),
+                   "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
+                   "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
+                   "sharding": "pair tiles dealt over %d rank(s), input replicated" % world},
+        "roofline": roof, "cpu_baseline": cpu, "spot_check": spot,
+        "device_bytes": eng.device_bytes(),
+        "ms_reduce": float(np.mean(red_ms)), "ms_engine_total": float(np.mean(tot_ms)),
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

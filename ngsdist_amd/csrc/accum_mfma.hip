@@ -20,16 +20,22 @@
 // the same time, which keeps the slice's operand panel in that XCD's L2.
 // Slices are written as slabs and summed in fixed order by reduce.hip
 // (deterministic; no floating-point atomics).
+#include <cstdlib>
+
 #include "ngd_internal.h"
 
 namespace {
 
 constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
-constexpr int DEPTH = 4;       // k-groups in flight per wavefront (<= NGD_KG_TAIL)
-static_assert(DEPTH <= NGD_KG_TAIL, "tail padding must cover the run-ahead");
 
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256, 2) void k_accum_mfma(
+// DEPTH = k-groups of operands in flight per wavefront (register ring, <= NGD_KG_TAIL);
+// WPS   = wavefronts per SIMD the register budget is held to (workgroups per CU).
+// One wavefront alone issues an f64 MFMA only every ~138 cycles (measured,
+// profiles/r01_fp64_peak_microbench.txt); the 64-cycle pipe rate needs two
+// wavefronts per SIMD that are BOTH in their MFMA phase, so a third resident
+// wavefront is what covers the others' load/wait/epilogue phases.
+template <bool WEIGHTED, int DEPTH, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
     const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad,
     uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
@@ -39,7 +45,8 @@ __global__ __launch_bounds__(256, 2) void k_accum_mfma(
   const uint32_t tile = q % n_tiles;
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
   const uint32_t ti = tiles[tile].ti, tj = tiles[tile].tj;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wi = wave >> 1, wj = wave & 1;
   if (ti == tj && wi > wj) return;  // strictly-lower sub-tile of a diagonal tile: never read
   const uint32_t ig0 = ti * NGD_IG_PER_TILE + wi * WM;
@@ -56,8 +63,9 @@ __global__ __launch_bounds__(256, 2) void k_accum_mfma(
     for (int n = 0; n < WN; n++) acc[m][n] = (ngd_d4){0, 0, 0, 0};
 
   const uint64_t kstride = (uint64_t)n_ig * 64;
-  const double *pa = PA + (uint64_t)ig0 * 64 + lane;
-  const double *pb = QB + (uint64_t)jg0 * 64 + lane;
+  const double *pa = PA + (uint64_t)ig0 * 64;  // wave-uniform bases (SGPR); the lane adds lane*8 bytes
+  const double *pb = QB + (uint64_t)jg0 * 64;
+  const uint32_t lane_off = lane * 8;
 
   double a[DEPTH][WM], bq[DEPTH][WN];
   uint32_t wq[DEPTH];
@@ -81,19 +89,19 @@ __global__ __launch_bounds__(256, 2) void k_accum_mfma(
     const double *xa = pa + kg * kstride;
     const double *xb = pb + kg * kstride;
     asm volatile(
-        "global_load_dwordx2 %0, %4, off\n\t"
-        "global_load_dwordx2 %1, %4, off offset:512\n\t"
-        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-        "global_load_dwordx2 %3, %4, off offset:1536"
+        "global_load_dwordx2 %0, %4, %5\n\t"
+        "global_load_dwordx2 %1, %4, %5 offset:512\n\t"
+        "global_load_dwordx2 %2, %4, %5 offset:1024\n\t"
+        "global_load_dwordx2 %3, %4, %5 offset:1536"
         : "=&v"(a[d][0]), "=&v"(a[d][1]), "=&v"(a[d][2]), "=&v"(a[d][3])
-        : "v"(xa));
+        : "v"(lane_off), "s"(xa));
     asm volatile(
-        "global_load_dwordx2 %0, %4, off\n\t"
-        "global_load_dwordx2 %1, %4, off offset:512\n\t"
-        "global_load_dwordx2 %2, %4, off offset:1024\n\t"
-        "global_load_dwordx2 %3, %4, off offset:1536"
+        "global_load_dwordx2 %0, %4, %5\n\t"
+        "global_load_dwordx2 %1, %4, %5 offset:512\n\t"
+        "global_load_dwordx2 %2, %4, %5 offset:1024\n\t"
+        "global_load_dwordx2 %3, %4, %5 offset:1536"
         : "=&v"(bq[d][0]), "=&v"(bq[d][1]), "=&v"(bq[d][2]), "=&v"(bq[d][3])
-        : "v"(xb));
+        : "v"(lane_off), "s"(xb));
     if (WEIGHTED) {
       const uint32_t *xw = ws + (kg * 4 + (uint64_t)(lane >> 4)) / 3;
       asm volatile("global_load_dword %0, %1, off" : "=&v"(wq[d]) : "v"(xw));
@@ -106,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_accum_mfma(
                  : "n"(LPF * (DEPTH - 1)));
   };
   static_assert(WM == 4 && WN == 4, "the asm fetch is written for 4+4 operands");
+  static_assert(DEPTH >= 1 && DEPTH <= NGD_KG_TAIL, "tail padding must cover the run-ahead");
 
   if (kg0 < kg1) {
 #pragma unroll
@@ -155,10 +164,21 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
   if (!n_tiles) return;
   dim3 grid(n_tiles * n_ks), block(256);  // n_ks is a multiple of 8 (see the deal above)
-  if (d_ws)
-    hipLaunchKernelGGL((k_accum_mfma<true>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, g.n_ig,
-                       g.n_pad, kg_per_slice, n_kg_eff, slab);
-  else
-    hipLaunchKernelGGL((k_accum_mfma<false>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles,
-                       g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);
+  static const int variant = [] {
+    const char *v = getenv("NGD_MFMA_VARIANT");
+    return v && *v ? atoi(v) : 0;
+  }();
+#define NGD_MFMA(W, D, P)                                                                          \
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, \
+                     g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
+  // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
+  // (profiles/r01_*): the third wavefront covers the others' load phases.
+  // variant 1: 4-deep register ring, 2 wavefronts per SIMD.
+  // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
+  if (d_ws) {
+    if (variant == 1) NGD_MFMA(true, 4, 2); else NGD_MFMA(true, 1, 3);
+  } else {
+    if (variant == 1) NGD_MFMA(false, 4, 2); else NGD_MFMA(false, 1, 3);
+  }
+#undef NGD_MFMA
 }

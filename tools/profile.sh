@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/profile.sh <tag> [bench args...] -- rocprofv3 evidence for one bench.py command:
+#   pass 0: --kernel-trace --stats          (per-kernel durations)
+#   pass 1..: one --pmc group per run       (HBM bytes, SQ/MFMA activity, L2/L1 hit rates)
+# Output under gpurun_out/prof_<tag>/; tools/pmc_summary.py condenses it for profiles/.
+set -u
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() { # name, rocprof args...
+  local name=$1; shift
+  rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" "${BENCH_ARGS[@]}" \
+      > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "pass $name failed (see $OUT/$name.err)"
+  echo "pass $name done"
+}
+BENCH_ARGS=("$@" --no_cpu)
+run kt --kernel-trace --stats
+run fetch --kernel-trace --pmc FETCH_SIZE
+run write --kernel-trace --pmc WRITE_SIZE
+run sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE
+run l2 --kernel-trace --pmc TCC_HIT TCC_MISS
+run l1 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ
+cd "$ROOT" && python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.md" && cat "$OUT/summary.md"
