@@ -57,6 +57,7 @@ def main():
     import torch.distributed as dist
 
     import ngsdist_amd as N
+    from ngsdist_amd.dist import merge_shards
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,9 +107,7 @@ def main():
                 t = eng.timing()
                 acc_ms.append(t["ms_accum"]); red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
                 pair_sites.append(t["pair_sites"])
-            if world > 1:  # disjoint shards: SUM == gather (x + 0 is exact)
-                dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
-                dist.reduce(d_cnt, dst=0, op=dist.ReduceOp.SUM)
+            merge_shards(d_sum, d_cnt, dst=0)  # one RCCL collective per array; disjoint shards
             if rank == 0:
                 h_sum.copy_(d_sum, non_blocking=True)
                 h_cnt.copy_(d_cnt, non_blocking=True)

@@ -146,6 +146,9 @@ void ngd_boot_block_map(uint32_t state[3], uint64_t n_blocks, uint64_t *block_ma
 /* geometry helpers */
 uint64_t ngd_n_pairs(uint64_t n_ind);
 uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
+/* the shard (0 .. shard_world-1) that computes pair i1 < i2: 128 x 128 pair tiles of
+ * the upper triangle, row-major, dealt round-robin.  Pure host arithmetic. */
+uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world);
 /* bytes of device memory the engine holds for this configuration */
 uint64_t ngd_device_bytes(const ngd_engine *e);
 

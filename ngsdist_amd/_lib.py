@@ -43,7 +43,7 @@ EXPORTS = [
     "ngd_last_error", "ngd_abi_version", "ngd_device_count", "ngd_create", "ngd_destroy",
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_synth_fill", "ngd_run",
     "ngd_run_device", "ngd_last_timing", "ngd_finish", "ngd_taus_seed", "ngd_taus_get",
-    "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes",
+    "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_shard_of_pair",
 ]
 
 _lib = None
@@ -97,6 +97,8 @@ def load():
     L.ngd_n_pairs.restype = u64
     L.ngd_pair_index.argtypes = [u64, u64, u64]
     L.ngd_pair_index.restype = u64
+    L.ngd_shard_of_pair.argtypes = [u64, u64, u64, C.c_uint32]
+    L.ngd_shard_of_pair.restype = C.c_uint32
     L.ngd_device_bytes.argtypes = [vp]
     L.ngd_device_bytes.restype = u64
     _lib = L

@@ -1,0 +1,586 @@
+// ngsdist_host.cpp -- command-line host of the MI355X engine.
+//
+// Keeps the ngsDist command line (reference parse_args.cpp:54-80, defaults
+// :6-37, checks :203-220), its input formats (read_data.cpp:13-116), its
+// preparation of the array gen_dist() reads (ngsDist.cpp:165-174) and its
+// output (ngsDist.cpp:282-287, "%.10f" cells joined by tabs), and hands the one
+// hot block -- `for i1<i2: threadpool_add(gen_dist_slave)` + wait,
+// ngsDist.cpp:244-269 -- to the engine through the C ABI of
+// include/ngsdist_amd.h.  Written from scratch against that behaviour; it
+// shares no code with the reference.
+//
+// Differences that are deliberate:
+//  * binary input is streamed through in site chunks (read -> prepare ->
+//    ngd_upload_sites), so the host never holds the n_ind x n_sites x 3 array;
+//  * preparation (log / normalise / call / exp, all on the host's libm so cells
+//    print identically) runs on --n_threads threads; it is per-element, so the
+//    result does not depend on the thread count;
+//  * bootstrap moves no data: the block map drawn from the reference's taus
+//    stream is handed to ngd_run();
+//  * a file name without a '.' is treated as binary instead of dereferencing
+//    NULL (ngsDist.cpp:82);
+//  * extra options: --n_gpus N (pair tiles dealt over N devices of this node),
+//    --device D (first device), --kernel auto|stream|mfma|em_fast|em_faithful.
+#include <getopt.h>
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/ngsdist_amd.h"
+
+static const char *kVersion = "ngsdist_amd 0.1 (ngsDist 1.0.10 command line)";
+static const double kInf = 1e15;          // INF, gen_func.hpp:15
+static const size_t kLineBuf = 500000;    // BUFF_LEN, gen_func.hpp:17
+
+struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
+  const char *in_geno = nullptr;
+  bool in_bin = false, in_probs = false, in_logscale = false;
+  uint64_t n_ind = 0, n_sites = 0, tot_sites = 0;
+  const char *in_labels = nullptr;
+  bool in_labels_header = false;
+  const char *in_pos = nullptr;
+  bool in_pos_header = false;
+  bool call_geno = false;
+  double N_thresh = 0, call_thresh = 0;
+  bool pairwise_del = false;
+  double score[9] = {0, 0.5, 1, 0.5, 0, 0.5, 1, 0.5, 0};  // parse_args.cpp:25-27
+  uint64_t evol_model = 1;
+  bool indep_geno = false;
+  uint64_t n_boot_rep = 0, boot_block_size = 1;
+  const char *out = nullptr;
+  unsigned n_threads = 1, verbose = 1, seed = 0;
+  // engine placement (not in the reference)
+  int n_gpus = 1, device = 0, kernel = NGD_KERNEL_AUTO;
+};
+
+// error(), gen_func.cpp:12-18: message, perror, exit(-1)
+[[noreturn]] static void die(const char *func, const char *msg) {
+  fflush(stdout);
+  fprintf(stderr, "\n=====\nERROR: [%s] %s\n=====\n\n", func, msg);
+  perror("\t");
+  fflush(stderr);
+  exit(-1);
+}
+
+static void die_engine(const char *func, int rc) {
+  std::string m = std::string("engine error ") + std::to_string(rc) + ": " + ngd_last_error();
+  die(func, m.c_str());
+}
+
+static const char *kModelNames[] = {"Raw p-distance", "Log transf. p-distance", "JC69", "K80", "F81",
+                                    "HKY85/F84", "TN93"};
+
+static void parse_cmd_args(Pars &p, int argc, char **argv) {
+  static struct option opts[] = {{"geno", required_argument, nullptr, 'g'},
+                                 {"probs", no_argument, nullptr, 'p'},
+                                 {"log_scale", no_argument, nullptr, 'l'},
+                                 {"n_ind", required_argument, nullptr, 'n'},
+                                 {"n_sites", required_argument, nullptr, 's'},
+                                 {"tot_sites", required_argument, nullptr, 'S'},
+                                 {"labels", required_argument, nullptr, 'L'},
+                                 {"labelsH", required_argument, nullptr, 'H'},
+                                 {"pos", required_argument, nullptr, 'a'},
+                                 {"posH", required_argument, nullptr, 'A'},
+                                 {"call_geno", no_argument, nullptr, 'c'},
+                                 {"N_thresh", required_argument, nullptr, 'N'},
+                                 {"call_thresh", required_argument, nullptr, 'C'},
+                                 {"pairwise_del", no_argument, nullptr, 'D'},
+                                 {"avg_nuc_dist", no_argument, nullptr, 'd'},
+                                 {"evol_model", required_argument, nullptr, 'm'},
+                                 {"indep_geno", no_argument, nullptr, 'I'},
+                                 {"n_boot_rep", required_argument, nullptr, 'b'},
+                                 {"boot_block_size", required_argument, nullptr, 'B'},
+                                 {"out", required_argument, nullptr, 'o'},
+                                 {"n_threads", required_argument, nullptr, 'x'},
+                                 {"verbose", required_argument, nullptr, 'V'},
+                                 {"seed", required_argument, nullptr, 'r'},
+                                 {"n_gpus", required_argument, nullptr, 1001},
+                                 {"device", required_argument, nullptr, 1002},
+                                 {"kernel", required_argument, nullptr, 1003},
+                                 {nullptr, 0, nullptr, 0}};
+  p.seed = (unsigned)time(nullptr);  // parse_args.cpp:35
+  int c;
+  while ((c = getopt_long_only(argc, argv, "g:pln:s:S:a:A:L:H:cN:C:Ddm:Ib:B:o:x:V:r:", opts, nullptr)) != -1) {
+    switch (c) {
+      case 'g': p.in_geno = optarg; break;
+      case 'p': p.in_probs = true; break;
+      case 'l': p.in_logscale = true; p.in_probs = true; break;  // --log_scale implies --probs
+      case 'n': p.n_ind = (uint64_t)atol(optarg); break;
+      case 's': p.n_sites = (uint64_t)atol(optarg); break;
+      case 'S': p.tot_sites = (uint64_t)atol(optarg); break;
+      case 'L': p.in_labels = optarg; p.in_labels_header = false; break;
+      case 'H': p.in_labels = optarg; p.in_labels_header = true; break;
+      case 'a': p.in_pos = optarg; p.in_pos_header = false; break;
+      case 'A': p.in_pos = optarg; p.in_pos_header = true; break;
+      case 'c': p.call_geno = true; break;
+      case 'N': p.N_thresh = atof(optarg); p.call_geno = true; break;    // -N / -C imply --call_geno
+      case 'C': p.call_thresh = atof(optarg); p.call_geno = true; break;
+      case 'D': p.pairwise_del = true; break;
+      case 'd': p.score[4] = 0.5; break;  // --avg_nuc_dist, parse_args.cpp:134-137
+      case 'm': p.evol_model = (uint64_t)atol(optarg); break;
+      case 'I': p.indep_geno = true; break;
+      case 'b': p.n_boot_rep = (uint64_t)atol(optarg); break;
+      case 'B': p.boot_block_size = (uint64_t)atol(optarg); break;
+      case 'o': p.out = optarg; break;
+      case 'x': p.n_threads = (unsigned)atoi(optarg); break;
+      case 'V': p.verbose = (unsigned)atoi(optarg); break;
+      case 'r': p.seed = (unsigned)atoi(optarg); break;
+      case 1001: p.n_gpus = atoi(optarg); break;
+      case 1002: p.device = atoi(optarg); break;
+      case 1003:
+        if (!strcmp(optarg, "auto")) p.kernel = NGD_KERNEL_AUTO;
+        else if (!strcmp(optarg, "stream")) p.kernel = NGD_KERNEL_STREAM;
+        else if (!strcmp(optarg, "mfma")) p.kernel = NGD_KERNEL_MFMA;
+        else if (!strcmp(optarg, "em_fast")) p.kernel = NGD_KERNEL_EM_FAST;
+        else if (!strcmp(optarg, "em_faithful")) p.kernel = NGD_KERNEL_EM_FAITHFUL;
+        else die(__FUNCTION__, "unknown --kernel");
+        break;
+      default: exit(-1);
+    }
+  }
+  if (p.verbose >= 1) {
+    fprintf(stderr, "==> Input Arguments:\n");
+    fprintf(stderr,
+            "\tgeno: %s\n\tprobs: %s\n\tlog_scale: %s\n\tn_ind: %lu\n\tn_sites: %lu\n\ttot_sites: %lu\n"
+            "\tlabels: %s (%s header)\n\tpositions: %s (%s header)\n\tcall_geno: %s\n\tN_thresh: %f\n"
+            "\tcall_thresh: %f\n\tpairwise_del: %s\n\tavg_nuc_dist: %s\n\tevol_model: %s\n\tgeno_indep: %s\n"
+            "\tn_boot_rep: %lu\n\tboot_block_size: %lu\n\tout: %s\n\tn_threads: %d\n\tverbose: %d\n\tseed: %d\n"
+            "\tversion: %s\n\n",
+            p.in_geno, p.in_probs ? "true" : "false", p.in_logscale ? "true" : "false", p.n_ind, p.n_sites,
+            p.tot_sites, p.in_labels, p.in_labels_header ? "WITH" : "WITHOUT", p.in_pos,
+            p.in_pos_header ? "WITH" : "WITHOUT", p.call_geno ? "true" : "false", p.N_thresh, p.call_thresh,
+            p.pairwise_del ? "true" : "false", p.score[4] == 0.5 ? "true" : "false",
+            p.evol_model <= 6 ? kModelNames[p.evol_model] : "?", p.indep_geno ? "true" : "false", p.n_boot_rep,
+            p.boot_block_size, p.out, p.n_threads, p.verbose, p.seed, kVersion);
+  }
+  if (p.verbose > 4)
+    fprintf(stderr, "==> Verbose values greater than 4 for debugging purpose only. Expect large amounts of info on screen\n");
+  // parse_args.cpp:203-220
+  if (!p.in_geno) die(__FUNCTION__, "genotype input file (--geno) missing!");
+  if (p.n_ind == 0) die(__FUNCTION__, "number of individuals (--n_ind) missing!");
+  if (p.n_sites == 0) die(__FUNCTION__, "number of sites (--n_sites) missing!");
+  if (p.tot_sites > 0 && p.pairwise_del)
+    die(__FUNCTION__, "cannot specify total number of sites (--tot_sites) with pairwise deletion (--pairwise_del)!");
+  if (p.call_geno && !p.in_probs) die(__FUNCTION__, "can only call genotypes from likelihoods/probabilities!");
+  if (p.evol_model > 6) die(__FUNCTION__, "invalid correction method specified!");
+  if (p.evol_model > 2 && !p.in_pos)
+    die(__FUNCTION__, "use of more complex evolutionary models requires position information!");
+  if (!p.out) die(__FUNCTION__, "output prefix (--out) missing!");
+  if (p.n_threads < 1) die(__FUNCTION__, "number of threads cannot be less than 1!");
+  if (p.n_gpus < 1) die(__FUNCTION__, "number of GPUs cannot be less than 1!");
+  if (p.boot_block_size < 1) die(__FUNCTION__, "bootstrap block size cannot be less than 1!");
+}
+
+// ---------------------------------------------------------------------------
+// text helpers with the reference's semantics
+// ---------------------------------------------------------------------------
+static gzFile open_gz(const char *name, const char *mode) {  // open_gzfile, gen_func.cpp:208-223
+  gzFile fh = strcmp(name, "-") == 0 ? gzdopen(fileno(stdin), mode) : gzopen(name, mode);
+  if (fh && gzbuffer(fh, 1 << 20) < 0) return nullptr;
+  return fh;
+}
+
+static void chomp(char *s) {  // gen_func.cpp:192-199: drops ONE trailing \n or \r
+  size_t n = strlen(s);
+  if (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) s[n - 1] = '\0';
+}
+
+// read_file(), gen_func.cpp:238-283: lines, minus empty ones and ones starting
+// with '#', minus `offset` leading ones; a final line without '\n' is lost to
+// the gzeof() check exactly as there.
+static std::vector<std::string> read_lines(const char *path, uint64_t offset) {
+  gzFile fh = open_gz(path, "r");
+  if (!fh) die("read_file", "cannot open file!");
+  std::vector<std::string> out;
+  std::vector<char> buf(kLineBuf);
+  for (;;) {
+    buf[0] = '\0';
+    gzgets(fh, buf.data(), (int)buf.size());
+    if (gzeof(fh)) break;
+    chomp(buf.data());
+    if (buf[0] == '\0' || buf[0] == '#') continue;
+    if (offset) { offset--; continue; }
+    out.emplace_back(buf.data());
+  }
+  gzclose(fh);
+  return out;
+}
+
+// split(str, " \t", double**), gen_func.cpp:390-417: tokens between separators,
+// empty tokens dropped, tokens that strtod does not consume entirely dropped.
+static void split_doubles(char *line, const char *sep, std::vector<double> &out) {
+  out.clear();
+  char *s = line;
+  while (s && *s) {
+    size_t len = strcspn(s, sep);
+    char *next = s[len] ? s + len + 1 : nullptr;
+    s[len] = '\0';
+    if (len) {
+      char *end;
+      double v = strtod(s, &end);
+      if (!*end) out.push_back(v);
+    }
+    s = next;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// preparation of one (individual, site): read_data.cpp:37-45 / :84-98, then
+// ngsDist.cpp:165-174.  Same operation order and libm calls as the reference.
+// ---------------------------------------------------------------------------
+static inline void post_prob3(double *l) {  // gen_func.cpp:920-932 with logsum :135-151
+  double M = l[0];
+  for (int i = 1; i < 3; i++) M = (l[i] >= M ? l[i] : M);
+  double norm;
+  if (M == -INFINITY) {
+    norm = -INFINITY;
+  } else {
+    double sum = 0;
+    for (int i = 0; i < 3; i++) sum += exp(l[i] - M);
+    norm = log(sum) + M;
+  }
+  for (int i = 0; i < 3; i++) l[i] -= norm;
+}
+
+static inline void call_geno3(double *l, double N_thresh, double call_thresh) {  // gen_func.cpp:886-914
+  if (N_thresh > call_thresh) die("call_geno", "missing data threshold must be smaller than calling genotype threshold!");
+  int max_pos = 0, min_pos = 0;
+  double mx = -INFINITY, mn = INFINITY;
+  for (int g = 0; g < 3; g++) if (l[g] > mx) { mx = l[g]; max_pos = g; }
+  for (int g = 0; g < 3; g++) if (l[g] < mn) { mn = l[g]; min_pos = g; }
+  double max_pp = exp(l[max_pos]);
+  if (l[min_pos] == l[max_pos]) max_pp = -1;
+  if (max_pp < N_thresh) for (int g = 0; g < 3; g++) l[g] = log((double)1 / 3);
+  if (max_pp >= call_thresh) {
+    for (int g = 0; g < 3; g++) l[g] = -kInf;
+    l[max_pos] = log(1);
+  }
+}
+
+static inline void finish_prep(const Pars &p, double *l) {  // ngsDist.cpp:165-174
+  if (p.call_geno) call_geno3(l, p.N_thresh, p.call_thresh);
+  for (int g = 0; g < 3; g++) l[g] = exp(l[g]);
+}
+
+// binary element; returns false on NaN (read_data.cpp:42-45)
+static inline bool prep_binary(const Pars &p, bool in_logscale, double *l) {
+  if (!in_logscale)
+    for (int g = 0; g < 3; g++) {
+      l[g] = log(l[g]);
+      if (l[g] == -INFINITY) l[g] = -kInf;  // conv_space, gen_func.cpp:123-130
+    }
+  post_prob3(l);
+  if (std::isnan(l[0]) || std::isnan(l[1]) || std::isnan(l[2])) return false;
+  finish_prep(p, l);
+  return true;
+}
+
+template <typename F>
+static void parallel_for(unsigned n_threads, uint64_t n, F fn) {
+  if (n_threads <= 1 || n < 4096) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  uint64_t per = (n + n_threads - 1) / n_threads;
+  for (unsigned t = 0; t < n_threads; t++) {
+    uint64_t lo = t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back(fn, lo, hi);
+  }
+  for (auto &t : th) t.join();
+}
+
+// ---------------------------------------------------------------------------
+struct Engines {
+  std::vector<ngd_engine *> e;
+  void upload_sites(const double *p, uint64_t s0, uint64_t n) {
+    for (auto *h : e) { int rc = ngd_upload_sites(h, p, s0, n); if (rc) die_engine("upload", rc); }
+  }
+  void commit() { for (auto *h : e) { int rc = ngd_commit(h); if (rc) die_engine("commit", rc); } }
+  ~Engines() { for (auto *h : e) ngd_destroy(h); }
+};
+
+// read_geno(), read_data.cpp:13-116, fused with the preparation and the upload
+static void load_and_upload(const Pars &p, Engines &eng) {
+  const uint64_t n_ind = p.n_ind, n_sites = p.n_sites;
+  gzFile fh = open_gz(p.in_geno, p.in_bin ? "rb" : "r");
+  if (!fh) die("read_geno", "cannot open GENO file!");
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_sites, (64ull << 20) / (n_ind * 24)));
+  std::vector<double> buf(chunk * n_ind * 3);
+  bool in_logscale = p.in_logscale;
+
+  if (p.in_bin) {
+    for (uint64_t s0 = 0; s0 < n_sites; s0 += chunk) {
+      const uint64_t n = std::min(chunk, n_sites - s0);
+      const uint64_t bytes = n * n_ind * 24;
+      uint64_t got = 0;
+      while (got < bytes) {
+        int r = gzread(fh, (char *)buf.data() + got, (unsigned)std::min<uint64_t>(bytes - got, 1u << 30));
+        if (r <= 0) break;
+        got += (uint64_t)r;
+      }
+      if (got != bytes) {
+        if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+        die("read_geno", "cannot read binary GENO file. Check GENO file and number of sites!");
+      }
+      std::atomic<bool> bad{false};
+      parallel_for(p.n_threads, n * n_ind, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t e = lo; e < hi; e++)
+          if (!prep_binary(p, in_logscale, &buf[3 * e])) bad = true;
+      });
+      if (bad) die("read_geno", "NaN found! Is the file format correct?");
+      eng.upload_sites(buf.data(), s0, n);
+    }
+  } else {
+    const uint64_t n_geno = p.in_probs ? 3 : 1;
+    std::vector<char> line(std::max<size_t>(kLineBuf, n_ind * n_geno * 32 + 4096));
+    std::vector<double> t;
+    uint64_t s = 0, filled = 0, s_base = 0;
+    auto flush = [&]() {
+      if (filled) eng.upload_sites(buf.data(), s_base, filled);
+      s_base += filled;
+      filled = 0;
+    };
+    while (s < n_sites) {
+      if (gzgets(fh, line.data(), (int)line.size()) == nullptr) {
+        if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+        die("read_geno", "cannot read GZip GENO file. Check GENO file and number of sites!");
+      }
+      chomp(line.data());
+      double *dst = &buf[filled * n_ind * 3];
+      if (line[0] == '\0') {
+        // empty line: the site keeps its -INF fill (read_data.cpp:21,58-59)
+        for (uint64_t i = 0; i < n_ind; i++) {
+          double *l = dst + 3 * i;
+          l[0] = l[1] = l[2] = -kInf;
+          finish_prep(p, l);
+        }
+      } else {
+        split_doubles(line.data(), " \t", t);
+        if (t.empty() || (s == 0 && t.size() < n_ind * n_geno)) {  // header
+          fprintf(stderr, "> Header found! Skipping line...\n");
+          continue;
+        }
+        if (t.size() < n_ind * n_geno) die("read_geno", "wrong GENO file format. Less fields than expected!");
+        const double *ptr = t.data() + (t.size() - n_ind * n_geno);  // last n_ind*n_geno columns
+        for (uint64_t i = 0; i < n_ind; i++) {
+          double *l = dst + 3 * i;
+          if (p.in_probs) {
+            for (int g = 0; g < 3; g++) l[g] = in_logscale ? ptr[3 * i + g] : log(ptr[3 * i + g]);
+          } else {
+            l[0] = l[1] = l[2] = -kInf;
+            int g = (int)ptr[i];
+            if (g >= 0) {
+              if (g > 2) die("read_geno", "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+              l[g] = log(1);
+            } else {
+              l[0] = l[1] = l[2] = log((double)1 / 3);
+            }
+          }
+          post_prob3(l);
+          finish_prep(p, l);
+        }
+      }
+      s++;
+      if (++filled == chunk) flush();
+    }
+    flush();
+  }
+  char one;
+  gzread(fh, &one, 1);
+  if (!gzeof(fh)) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
+  gzclose(fh);
+  eng.commit();
+}
+
+int main(int argc, char **argv) {
+  Pars pars;
+  parse_cmd_args(pars, argc, argv);
+  Pars &p = pars;
+
+  const uint64_t n_comb = ngd_n_pairs(p.n_ind);
+  if (p.verbose >= 1) fprintf(stderr, "==> Analysis will be run in %lu combinations\n", n_comb);
+  // ngsDist.cpp:55-65
+  if (!p.in_probs && !p.indep_geno) {
+    fprintf(stderr, "==> Using faster algorithm (assuming independence of genotypes) since input are genotypes!\n");
+    p.indep_geno = true;
+  } else if (p.call_geno && !p.indep_geno) {
+    fprintf(stderr, "==> Using faster algorithm (assuming independence of genotypes) since calling genotypes!\n");
+    p.indep_geno = true;
+  } else if (p.indep_geno && p.verbose >= 1) {
+    fprintf(stderr, "==> Using faster algorithm (assuming independence of genotypes)!\n");
+  }
+  // ngsDist.cpp:73-95
+  if (strcmp(p.in_geno, "-") == 0) {
+    if (p.verbose >= 1) fprintf(stderr, "==> Reading from STDIN (BINARY)\n");
+    p.in_bin = true;
+  } else {
+    struct stat st;
+    if (stat(p.in_geno, &st) != 0) die(__FUNCTION__, "cannot check GENO file size!");
+    const char *dot = strrchr(p.in_geno, '.');
+    if (dot && strcmp(dot, ".gz") == 0) {
+      if (p.verbose >= 1) fprintf(stderr, "==> GZIP input file (never BINARY)\n");
+      p.in_bin = false;
+    } else {
+      if (p.verbose >= 1) fprintf(stderr, "==> BINARY input file\n");
+      p.in_bin = true;
+      p.in_probs = true;
+      if (p.n_sites != (uint64_t)st.st_size / sizeof(double) / p.n_ind / 3)
+        die(__FUNCTION__, "invalid/corrupt genotype input file!");
+    }
+  }
+  if (p.evol_model > 2) {  // gen_dist() would error() on the first pair, ngsDist.cpp:387-398
+    static const char *msg[] = {"K80 model not yet supported", "F81 model not yet supported",
+                                "HKY85 model not yet supported", "TN93 model not yet supported"};
+    die("gen_dist", msg[p.evol_model - 3]);
+  }
+
+  // labels, ngsDist.cpp:103-125
+  std::vector<std::string> labels;
+  if (p.in_labels) {
+    if (p.verbose >= 1) fprintf(stderr, "==> Reading labels\n");
+    labels = read_lines(p.in_labels, p.in_labels_header ? 1 : 0);
+    if (labels.size() != p.n_ind) die(__FUNCTION__, "invalid LABELS file!");
+    for (auto &l : labels) {
+      size_t tab = l.find('\t');
+      if (tab != std::string::npos) l.resize(tab);
+    }
+  } else {
+    for (uint64_t i = 0; i < p.n_ind; i++) labels.push_back("Ind_" + std::to_string(i));
+  }
+  if (p.verbose >= 4) for (auto &l : labels) fprintf(stderr, "%s\n", l.c_str());
+
+  // positions: validated, never used (models 3-6 are unimplemented), ngsDist.cpp:133-149
+  if (p.in_pos) {
+    if (p.verbose >= 1) fprintf(stderr, "==> Reading positions file\n");
+    std::vector<std::string> pos = read_lines(p.in_pos, p.in_pos_header ? 1 : 0);
+    uint64_t n_fields = 0;
+    for (auto &l : pos) {
+      uint64_t n = 1 + (uint64_t)std::count(l.begin(), l.end(), '\t');
+      if (!l.empty() && l.back() == '\t') n--;  // no trailing empty field (_strtok, gen_func.cpp:305-322)
+      if (n_fields == 0) n_fields = n;
+      if (n != n_fields) die("read_split", "invalid number of fields in file!");
+    }
+    if (pos.size() != p.n_sites || n_fields < 2) die(__FUNCTION__, "invalid POS file!");
+  }
+
+  // engines: pair tiles dealt over --n_gpus devices, input replicated
+  int n_dev = ngd_device_count();
+  if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
+  if (p.device + p.n_gpus > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
+  Engines eng;
+  for (int r = 0; r < p.n_gpus; r++) {
+    ngd_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.n_ind = p.n_ind;
+    cfg.n_sites = p.n_sites;
+    memcpy(cfg.score, p.score, sizeof(cfg.score));
+    cfg.pairwise_del = p.pairwise_del;
+    cfg.indep_geno = p.indep_geno;
+    cfg.device = p.device + r;
+    cfg.kernel = p.kernel;
+    cfg.shard_rank = (uint32_t)r;
+    cfg.shard_world = (uint32_t)p.n_gpus;
+    ngd_engine *h = nullptr;
+    int rc = ngd_create(&cfg, &h);
+    if (rc) die_engine("ngd_create", rc);
+    eng.e.push_back(h);
+  }
+
+  if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
+  load_and_upload(p, eng);
+
+  if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
+  uint32_t rng[3];
+  ngd_taus_seed(rng, p.seed);  // gsl_rng_alloc(gsl_rng_taus) + gsl_rng_set, ngsDist.cpp:179-180
+
+  FILE *out_fh = fopen(p.out, "w");
+  if (!out_fh) die(__FUNCTION__, "cannot open output file!");
+
+  std::vector<double> sum(n_comb), part(n_comb), dist(n_comb);
+  std::vector<uint64_t> cnt(n_comb), cpart(n_comb), block_map;
+  std::vector<double> matrix(p.n_ind * p.n_ind, 0.0);  // zero diagonal, reused across replicates (:200)
+  std::string row;
+  uint64_t n_sites = p.n_sites;
+
+  fflush(stdout);
+  for (uint64_t rep = 0; rep <= p.n_boot_rep; rep++) {
+    if (p.verbose >= 1) {
+      if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
+      else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
+    }
+    if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
+    const uint64_t *bm = nullptr;
+    uint64_t n_blocks = 0;
+    if (rep > 0) {  // ngsDist.cpp:235-238
+      n_sites -= n_sites % p.boot_block_size;
+      n_blocks = n_sites / p.boot_block_size;
+      block_map.resize(n_blocks);
+      ngd_boot_block_map(rng, n_blocks, block_map.data());
+      bm = block_map.data();
+      if (p.verbose >= 5)
+        for (uint64_t b = 0; b < n_blocks; b++)
+          for (uint64_t s = 0; s < p.boot_block_size; s++)
+            fprintf(stderr, "block: %lu\torig_site: %lu\trand_block:%lu\trand_site: %lu\n", b,
+                    b * p.boot_block_size + s, block_map[b], block_map[b] * p.boot_block_size + s);
+    }
+    if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
+    if (eng.e.size() == 1) {
+      int rc = ngd_run(eng.e[0], bm, n_blocks, p.boot_block_size, sum.data(), cnt.data());
+      if (rc) die_engine("ngd_run", rc);
+    } else {
+      // one host thread per device; shards are disjoint, so merging is x + 0
+      std::vector<std::vector<double>> ps(eng.e.size(), std::vector<double>(n_comb));
+      std::vector<std::vector<uint64_t>> pc(eng.e.size(), std::vector<uint64_t>(n_comb));
+      std::vector<int> rcs(eng.e.size(), 0);
+      std::vector<std::thread> th;
+      for (size_t r = 0; r < eng.e.size(); r++)
+        th.emplace_back([&, r]() { rcs[r] = ngd_run(eng.e[r], bm, n_blocks, p.boot_block_size, ps[r].data(), pc[r].data()); });
+      for (auto &t : th) t.join();
+      for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine("ngd_run", rcs[r]);
+      std::fill(sum.begin(), sum.end(), 0.0);
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (size_t r = 0; r < eng.e.size(); r++)
+        for (uint64_t k = 0; k < n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
+    }
+    if (p.verbose >= 3) {  // the per-pair line of ngsDist.cpp:366-367
+      uint64_t k = 0;
+      for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
+        for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
+          fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
+                  sum[k], cnt[k], sum[k] / (double)cnt[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
+    }
+    int rc = ngd_finish(sum.data(), cnt.data(), n_comb, p.tot_sites, p.evol_model, dist.data());
+    if (rc) die("gen_dist", "invalid evolutionary model specified!");
+    uint64_t k = 0;
+    for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
+      for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
+        matrix[i1 * p.n_ind + i2] = matrix[i2 * p.n_ind + i1] = dist[k];  // gen_dist_slave, :408-412
+
+    if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
+    fprintf(out_fh, "\n%lu\n", p.n_ind);  // ngsDist.cpp:282-287
+    char cell[64];
+    for (uint64_t i = 0; i < p.n_ind; i++) {
+      row.assign(labels[i]);
+      for (uint64_t j = 0; j < p.n_ind; j++) {
+        snprintf(cell, sizeof(cell), "\t%.10f", matrix[i * p.n_ind + j]);  // join(), gen_func.cpp:479-496
+        row += cell;
+      }
+      row += '\n';
+      fwrite(row.data(), 1, row.size(), out_fh);
+    }
+  }
+  fclose(out_fh);
+  if (p.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
+  if (p.verbose >= 1) fprintf(stderr, "Done!\n");
+  return 0;
+}

@@ -47,6 +47,15 @@ void ngd_boot_block_map(uint32_t st[3], uint64_t n_blocks, uint64_t *block_map) 
   }
 }
 
+// Which shard computes pair (i1 < i2): pair tiles of 128 x 128 individuals, upper
+// triangle enumerated row-major, dealt round-robin (the same rule ngd_create uses).
+uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world) {
+  if (shard_world <= 1) return 0;
+  const uint64_t n_t = (n_ind + 127) / 128, ti = i1 / 128, tj = i2 / 128;
+  const uint64_t tid = ti * n_t - ti * (ti - 1) / 2 - ti + tj;  // sum_{r<ti}(n_t - r) + (tj - ti)
+  return (uint32_t)(tid % shard_world);
+}
+
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites,
                uint64_t evol_model, double *dist) {
   if (evol_model > 2) return NGD_E_MODEL;  // reference: error("... model not yet supported")

@@ -1,0 +1,32 @@
+"""Multi-GPU plumbing: one process per GPU, pair tiles dealt over ranks, inputs
+replicated, and ONE collective at the end that brings the disjoint shards to
+rank 0.  Because every pair is owned by exactly one rank and the others hold
+exact zeros, a SUM reduce is a gather: x + 0 is exact in IEEE arithmetic (sums
+are >= +0, so no -0 ambiguity).  Backend "nccl" (= RCCL over xGMI) on GPUs,
+"gloo" in the CPU tests.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def shard_of_pairs(n_ind, world):
+    """owner rank of every pair, in the reference's pair order"""
+    L = _lib.load()
+    out = np.empty(n_ind * (n_ind - 1) // 2, dtype=np.int32)
+    k = 0
+    for i in range(n_ind):
+        for j in range(i + 1, n_ind):
+            out[k] = L.ngd_shard_of_pair(n_ind, i, j, world)
+            k += 1
+    return out
+
+
+def merge_shards(sum_t, cnt_t, dst=0):
+    """In-place: after the call rank `dst` holds every pair.  sum_t float64,
+    cnt_t int64 torch tensors (device tensors under RCCL, CPU tensors under gloo)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    dist.reduce(sum_t, dst=dst, op=dist.ReduceOp.SUM)
+    dist.reduce(cnt_t, dst=dst, op=dist.ReduceOp.SUM)

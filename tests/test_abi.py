@@ -1,0 +1,116 @@
+"""CPU checks of the C-ABI library: it loads, exports every symbol the header
+declares, and its host-side functions (no GPU involved) agree with the oracle.
+No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.environ.setdefault("NGD_NO_TORCH", "1")  # the ABI must load without PyTorch
+    from ngsdist_amd import _lib
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "ngsdist_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ngd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from ngsdist_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "missing export " + s
+    assert sorted(_lib.EXPORTS) == syms, "binding list and header drifted apart"
+
+
+def test_signatures_are_plain_c():
+    txt = open(os.path.join(ROOT, "include", "ngsdist_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # declarations only
+    for banned in ("torch", "hipStream_t", "std::", "at::Tensor", "#include <hip"):
+        assert banned not in txt
+
+
+def test_abi_version_and_struct_sizes(lib):
+    from ngsdist_amd import _lib
+    assert lib.ngd_abi_version() == 1
+    assert C.sizeof(_lib.NgdConfig) == 8 + 8 + 72 + 4 * 4 + 2 * 4 + 6 * 4
+    assert C.sizeof(_lib.NgdTiming) == 4 * 8 + 2 * 8
+
+
+def test_no_device_is_an_error_code_not_a_crash(lib):
+    import ngsdist_amd as N
+    if N.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(N.NgdError) as ei:
+        N.Engine(6, 200)
+    assert ei.value.code == -2 and "no HIP device" in str(ei.value)
+
+
+def test_taus_through_the_abi_matches_gsl_known_answer():
+    import ngsdist_amd as N
+    t = N.Taus(1)
+    k = 0
+    for _ in range(10000):
+        k = t.get()
+    assert k == 2733957125  # GSL rng/test.c
+    a, b = N.Taus(12345), O.Taus(12345)
+    assert [a.uniform() for _ in range(100)] == [b.uniform() for _ in range(100)]
+    a, b = N.Taus(7), O.Taus(7)
+    for nb in (1, 28, 1000):
+        assert np.array_equal(a.block_map(nb), b.block_map(nb))
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_finish_matches_oracle_bitwise(model):
+    import ngsdist_amd as N
+    rng = np.random.default_rng(3)
+    cnt = rng.integers(1, 1000, size=500).astype(np.uint64)
+    s = rng.random(500) * cnt
+    s[:6] = [0.0, cnt[1], 0.75 * cnt[2], 0.9 * cnt[3], 89.5, 0.0]
+    cnt[5] = 0  # 0/0
+    for tot in (0, 1234):
+        with np.errstate(all="ignore"):
+            a = N.finish(s, cnt, tot, model)
+            b = O.finish(s, cnt, tot, model)
+        assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(np.signbit(a), np.signbit(b))  # -0.0 and -nan print differently
+        assert [O.fmt_cell(x) for x in a[:8]] == [O.fmt_cell(x) for x in b[:8]]
+
+
+def test_finish_rejects_unimplemented_models():
+    import ngsdist_amd as N
+    for m in (3, 4, 5, 6, 7):
+        with pytest.raises(N.NgdError) as ei:
+            N.finish(np.ones(2), np.ones(2, dtype=np.uint64), 0, m)
+        assert ei.value.code == -5
+
+
+def test_pair_index_is_row_major_upper_triangle(lib):
+    n = 7
+    k = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert lib.ngd_pair_index(n, i, j) == k
+            k += 1
+    assert lib.ngd_n_pairs(n) == k
+
+
+def test_shard_of_pair_partitions(lib):
+    n = 300  # 3 tile rows -> 6 tiles
+    for world in (1, 2, 3, 8):
+        owners = {lib.ngd_shard_of_pair(n, i, j, world) for i in (0, 127, 128, 299) for j in range(i + 1, n, 37)}
+        assert owners <= set(range(world))
+    assert lib.ngd_shard_of_pair(n, 0, 1, 4) == 0 and lib.ngd_shard_of_pair(n, 0, 128, 4) == 1
+    assert lib.ngd_shard_of_pair(n, 128, 129, 4) == 3 and lib.ngd_shard_of_pair(n, 256, 257, 4) == 5 % 4

@@ -1,0 +1,71 @@
+"""The N>1 path on CPU: two gloo ranks, pair tiles dealt by the engine's own
+rule (ngd_shard_of_pair), each rank fills only the pairs it owns, and ONE
+collective (ngsdist_amd.dist.merge_shards, the function bench.py uses over
+RCCL) brings everything to rank 0 -- bit-identical to the single-rank result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_ind, n_sites, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from ngsdist_amd.dist import merge_shards, shard_of_pairs
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = O.synth_indmajor(13, n_ind, n_sites, miss_frac=0.1)
+    full_s, full_c = O.all_pairs(p, pairwise_del=True)  # stand-in for the device kernels
+    owner = shard_of_pairs(n_ind, world)
+    mine = owner == rank
+    s = torch.from_numpy(np.where(mine, full_s, 0.0))
+    c = torch.from_numpy(np.where(mine, full_c, 0).astype(np.int64))
+    merge_shards(s, c, dst=0)
+    if rank == 0:
+        q.put((np.array_equal(s.numpy(), full_s), np.array_equal(c.numpy().astype(np.uint64), full_c),
+               int(mine.sum()), int((~mine).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_is_bit_exact():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_ind, n_sites = 300, 64  # 3 tile rows -> 6 tiles over 2 ranks
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ind, n_sites, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    ok_s, ok_c, n_mine, n_other = q.get(timeout=10)
+    assert ok_s and ok_c
+    assert n_mine > 0 and n_other > 0  # both ranks really owned something
+
+
+def test_shard_owner_covers_every_pair_once():
+    os.environ.setdefault("NGD_NO_TORCH", "1")
+    from ngsdist_amd.dist import shard_of_pairs
+    for world in (1, 2, 4, 8):
+        o = shard_of_pairs(260, world)
+        assert o.min() >= 0 and o.max() < world
+        if world <= 6:
+            assert len(set(o.tolist())) == min(world, 6)

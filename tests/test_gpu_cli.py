@@ -1,0 +1,139 @@
+"""End to end through the C++ host (ngsdist_amd/bin/ngsDist): same command line
+as the reference, byte-identical .dist files.  Expected bytes come from (a) the
+reference outputs kept under tests/golden/survey_probe and (b) the CPU oracle
+run on the same inputs (oracle.run_reference_flow = the reference's main loop).
+"""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "ngsdist_amd", "bin", "ngsDist")
+SP = os.path.join(ROOT, "tests", "golden", "survey_probe")
+
+
+def cli(tmp_path, *args, stdin=None, name="out.dist"):
+    out = str(tmp_path / name)
+    r = subprocess.run([BIN] + [str(a) for a in args] + ["--out", out, "--verbose", "0"], capture_output=True,
+                       input=stdin)
+    assert r.returncode == 0, r.stderr.decode()
+    with open(out) as fh:
+        return fh.read()
+
+
+def golden(name):
+    with open(os.path.join(SP, name)) as fh:
+        return fh.read()
+
+
+T_GL = os.path.join(SP, "t_gl.bin")
+
+
+def test_golden_outputs_of_the_reference(tmp_path):
+    assert cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno",
+               "--evol_model", 0) == golden("t_gl_I0.dist")
+    assert cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200,
+               "--evol_model", 2) == golden("t_gl_EM2.dist")
+    assert cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--call_geno",
+               "--evol_model", 0) == golden("t_gl_CG.dist")
+    assert cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno", "--n_boot_rep", 2,
+               "--boot_block_size", 7, "--seed", 12345) == golden("t_gl_B.dist")
+    assert cli(tmp_path, "--geno", os.path.join(SP, "t_geno.gz"), "--n_ind", 6, "--n_sites", 200) == golden("t_T.dist")
+    assert cli(tmp_path, "--geno", os.path.join(SP, "id.geno.gz"), "--n_ind", 3, "--n_sites", 4) == golden("id.dist")
+    assert cli(tmp_path, "--geno", os.path.join(SP, "id.geno.gz"), "--n_ind", 3, "--n_sites", 4,
+               "--pairwise_del") == golden("id2.dist")
+    assert cli(tmp_path, "--geno", os.path.join(SP, "far.geno.gz"), "--n_ind", 2, "--n_sites", 2) == golden("far.dist")
+
+
+def test_every_kernel_prints_the_same_bytes(tmp_path):
+    base = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200]
+    for k in ("stream", "mfma"):
+        assert cli(tmp_path, *base, "--indep_geno", "--evol_model", 0, "--kernel", k) == golden("t_gl_I0.dist")
+    for k in ("em_fast", "em_faithful"):
+        assert cli(tmp_path, *base, "--evol_model", 2, "--kernel", k) == golden("t_gl_EM2.dist")
+
+
+def test_stdin_binary_and_log_scale(tmp_path):
+    raw = np.fromfile(T_GL, dtype=np.float64)
+    exp = golden("t_gl_I0.dist")
+    assert cli(tmp_path, "--geno", "-", "--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno", "--evol_model", 0,
+               stdin=raw.tobytes()) == exp
+    logf = tmp_path / "t_log.bin"
+    np.log(raw).tofile(str(logf))
+    p = O.prep_binary(np.log(raw), 6, 200, in_logscale=True)
+    assert cli(tmp_path, "--geno", logf, "--log_scale", "--n_ind", 6, "--n_sites", 200, "--indep_geno",
+               "--evol_model", 0) == O.run_reference_flow(p, evol_model=0)
+
+
+@pytest.mark.parametrize("flags,kw", [
+    (["--call_geno", "--N_thresh", "0.3", "--call_thresh", "0.9"], dict(call=(0.3, 0.9))),
+    (["--call_geno", "--pairwise_del", "--N_thresh", "0.5", "--call_thresh", "0.9"], dict(call=(0.5, 0.9), pairwise_del=True)),
+    (["--indep_geno", "--avg_nuc_dist", "--evol_model", "2"], dict(avg=True, evol_model=2)),
+    (["--indep_geno", "--tot_sites", "1000", "--evol_model", "0"], dict(tot_sites=1000, evol_model=0)),
+    (["--pairwise_del", "--evol_model", "1"], dict(pairwise_del=True, indep_geno=False)),
+    (["--indep_geno", "--n_boot_rep", "3", "--boot_block_size", "1", "--seed", "99"], dict(n_boot_rep=3, boot_block_size=1, seed=99)),
+    (["--n_boot_rep", "2", "--boot_block_size", "16", "--seed", "5", "--evol_model", "2"],
+     dict(n_boot_rep=2, boot_block_size=16, seed=5, indep_geno=False, evol_model=2)),
+])
+def test_flag_combinations_against_oracle_flow(tmp_path, flags, kw):
+    raw = np.fromfile(T_GL, dtype=np.float64)
+    call = kw.pop("call", None)
+    avg = kw.pop("avg", False)
+    p = O.prep_binary(raw, 6, 200, call_geno=call is not None, N_thresh=call[0] if call else 0,
+                      call_thresh=call[1] if call else 0)
+    kw.setdefault("indep_geno", True)
+    exp = O.run_reference_flow(p, score=O.score_matrix(avg), **kw)
+    got = cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, *flags)
+    assert got == exp
+
+
+def _testA_like(tmp_path, n_ind=24, n_sites=10000, seed=4):
+    """examples/test.sh testA shape: called genotypes, gz TSV with two prefix columns,
+    labels with awkward characters (examples/testA.labels style)."""
+    rng = np.random.default_rng(seed)
+    freq = rng.uniform(0.05, 0.5, size=n_sites)
+    g = (rng.random((n_sites, n_ind, 2)) < freq[:, None, None]).sum(axis=2)
+    g[rng.random((n_sites, n_ind)) < 0.02] = -1
+    path = tmp_path / "testA_T.geno.gz"
+    with gzip.open(str(path), "wt") as fh:
+        for s in range(n_sites):
+            fh.write("chrSIM\t%d\t" % (s + 1) + "\t".join(str(int(x)) for x in g[s]) + "\n")
+    labels = ["pop%d_ind%d%s" % (i // 8, i, "*+#"[i % 3]) + ("\textra" if i % 5 == 0 else "") for i in range(n_ind)]
+    lpath = tmp_path / "testA.labels"
+    lpath.write_text("\n".join(labels) + "\n")
+    return str(path), str(lpath), [l.split("\t")[0] for l in labels]
+
+
+def test_testA_shape_called_genotypes(tmp_path):
+    path, lpath, labels = _testA_like(tmp_path)
+    p = O.load_text(path, 24, 10000, in_probs=False)
+    for extra, kw in ((["--n_threads", "10", "--seed", "12345"], {}),
+                      (["--seed", "12345", "--n_boot_rep", "5"], dict(n_boot_rep=5)),
+                      (["--seed", "12345", "--n_boot_rep", "5", "--boot_block_size", "10"],
+                       dict(n_boot_rep=5, boot_block_size=10))):
+        exp = O.run_reference_flow(p, labels=labels, seed=12345, n_threads=8, **kw)
+        got = cli(tmp_path, "--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, *extra)
+        assert hashlib.md5(got.encode()).hexdigest() == hashlib.md5(exp.encode()).hexdigest()
+        assert got == exp
+
+
+def test_text_gl_with_header_and_two_gpu_shards_on_one_device(tmp_path):
+    n_ind, n_sites = 150, 300  # two tile rows -> 3 pair tiles
+    p_raw = O.synth_indmajor(31, n_ind, n_sites)  # [i][s][3]
+    path = tmp_path / "gl.beagle.gz"
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("marker\tallele1\tallele2\t" + "\t".join("Ind%d" % (i // 3) for i in range(3 * n_ind)) + "\n")
+        for s in range(n_sites):
+            fh.write("chr_%d\t0\t1\t" % s + "\t".join("%.17g" % v for v in p_raw[:, s, :].reshape(-1)) + "\n")
+    p = O.load_text(str(path), n_ind, n_sites, in_probs=True)
+    exp = O.run_reference_flow(p, evol_model=1, indep_geno=True, n_threads=8)
+    got = cli(tmp_path, "--geno", path, "--probs", "--n_ind", n_ind, "--n_sites", n_sites, "--indep_geno")
+    assert got == exp
