@@ -371,8 +371,12 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
                               e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
       break;
     case NGD_KERNEL_MFMA:
-      ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
-                            g.n_kg, e->slab);
+      if (env_u64("NGD_MFMA_VARIANT", 0) == 2)
+        ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
+                                  g.n_kg, e->slab);
+      else
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
+                              g.n_kg, e->slab);
       break;
     default:
       ngd_launch_accum_em(e->st, g, e->PA, ws, n_eff, e->sc, e->cfg.pairwise_del,

@@ -28,7 +28,10 @@ for j in sorted(glob.glob(os.path.join(out, "kt.json"))):
         print("(no bench line: %r)\n" % exc)
 
 stats = glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True)
+kt_ms = {}
 if stats:
+    for r in csv.DictReader(open(stats[0])):
+        kt_ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
     print("## --kernel-trace --stats\n")
     print("| kernel | calls | avg ms | min ms | max ms | % |")
     print("|---|---|---|---|---|---|")
@@ -82,4 +85,7 @@ for k in sorted({k for (k, _) in agg}):
         print("- SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES = %.3f" % (g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES")))
     if g("GRBM_GUI_ACTIVE"):
         print("- GRBM_GUI_ACTIVE per launch = %.4g (sum over 8 XCDs)" % g("GRBM_GUI_ACTIVE"))
+        if k in kt_ms:
+            print("- effective shader clock = GRBM_GUI_ACTIVE / 8 / kernel time = %.0f MHz (kernel %.3f ms)" % (
+                g("GRBM_GUI_ACTIVE") / 8 / (kt_ms[k] * 1e-3) / 1e6, kt_ms[k]))
     print()

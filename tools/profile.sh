@@ -16,10 +16,15 @@ run() { # name, rocprof args...
   echo "pass $name done"
 }
 BENCH_ARGS=("$@" --no_cpu)
-run kt --kernel-trace --stats
-run fetch --kernel-trace --pmc FETCH_SIZE
-run write --kernel-trace --pmc WRITE_SIZE
-run sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE
-run l2 --kernel-trace --pmc TCC_HIT TCC_MISS
-run l1 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ
+PASSES=${PASSES:-"kt fetch write sq l2 l1"}
+for p in $PASSES; do
+  case $p in
+    kt) run kt --kernel-trace --stats ;;
+    fetch) run fetch --kernel-trace --pmc FETCH_SIZE ;;
+    write) run write --kernel-trace --pmc WRITE_SIZE ;;
+    sq) run sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE ;;
+    l2) run l2 --kernel-trace --pmc TCC_HIT TCC_MISS ;;
+    l1) run l1 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ ;;
+  esac
+done
 cd "$ROOT" && python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.md" && cat "$OUT/summary.md"
