@@ -126,6 +126,12 @@ int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
 int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
                    uint64_t block_size, void *d_sum, void *d_cnt);
 
+/* Bootstrap replicates re-use per-block partial sums computed on the first
+ * ngd_run() that carries a block map (valid for that block size / block count;
+ * recomputed automatically when either changes).  This forgets them, so that a
+ * benchmark can charge the partial-sum pass to every timed step. */
+int ngd_drop_caches(ngd_engine *e);
+
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
 
 /* The tail of gen_dist(), ngsDist.cpp:372-401, on the HOST with the host's

@@ -124,16 +124,18 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
         arrive(d);
-        if (WEIGHTED) {  // bootstrap multiplicity of the site (ngsDist.cpp:426-434)
-          const double w = (double)wq[d];
+        if (DEPTH == 1 || kg + d < kg1) {  // a slice need not be a whole number of ring trips
+          if (WEIGHTED) {  // bootstrap multiplicity of the site (ngsDist.cpp:426-434)
+            const double w = (double)wq[d];
 #pragma unroll
-          for (int m = 0; m < WM; m++) a[d][m] *= w;
+            for (int m = 0; m < WM; m++) a[d][m] *= w;
+          }
+#pragma unroll
+          for (int m = 0; m < WM; m++)
+#pragma unroll
+            for (int n = 0; n < WN; n++)
+              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
-#pragma unroll
-        for (int m = 0; m < WM; m++)
-#pragma unroll
-          for (int n = 0; n < WN; n++)
-            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
         fetch(d, kg + d + DEPTH);
         __builtin_amdgcn_sched_barrier(0);

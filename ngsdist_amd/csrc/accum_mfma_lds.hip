@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 3) void k_accum_mfma_lds(
   const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
   if (kg1 > n_kg) kg1 = n_kg;
-  const uint32_t n_stage = kg0 < kg1 ? (uint32_t)((kg1 - kg0 + KC - 1) / KC) : 0;  // slices are multiples of 4 k-groups
+  const uint32_t n_stage = kg0 < kg1 ? (uint32_t)((kg1 - kg0 + KC - 1) / KC) : 0;
 
   ngd_d4 acc[WM][WN];
 #pragma unroll
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 3) void k_accum_mfma_lds(
         const uint32_t slot = t % NS;
 #pragma unroll
         for (int kgl = 0; kgl < KC; kgl++) {
+          if (kg0 + (uint64_t)t * KC + kgl >= kg1) break;  // slice not a whole number of stages
           double a[WM], bq[WN];
 #pragma unroll
           for (int m = 0; m < WM; m++) a[m] = ring[slot][kgl][0][wi * WM + m][lane];

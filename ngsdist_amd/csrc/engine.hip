@@ -54,6 +54,10 @@ struct ngd_engine {
   uint64_t per_slice = 0;
   double *d_sum = nullptr;
   unsigned long long *d_cnt = nullptr;
+  // bootstrap by per-block partial sums (valid while boot_B != 0)
+  double *slab_boot = nullptr, *d_wslice = nullptr;
+  uint64_t boot_B = 0, boot_blocks = 0, boot_per_slice = 0, slab_boot_elems = 0;
+  uint32_t boot_nks = 0, boot_sub = 0;
   double *staging = nullptr;
   uint64_t staging_sites = 0;
   bool committed = false;
@@ -96,7 +100,8 @@ void ngd_destroy(ngd_engine *e) {
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_block_map, e->d_mult, e->d_ws,
-                  e->d_tiles, e->d_tiles16, e->d_pairs, e->slab, e->d_sum, e->d_cnt, e->staging};
+                  e->d_tiles, e->d_tiles16, e->d_pairs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
+                  e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (auto &v : e->ev)
@@ -333,13 +338,14 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
 
+  std::vector<uint32_t> mult;
   HIPCHK(hipEventRecord(e->ev[0], e->st));
   if (block_map) {
     if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
     if (n_blocks > g.n_sites / block_size)
       return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
     n_eff = n_blocks * block_size;
-    std::vector<uint32_t> mult(n_blocks, 0);
+    mult.assign(n_blocks, 0);
     uint32_t mx = 0;
     for (uint64_t b = 0; b < n_blocks; b++) {
       if (block_map[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
@@ -364,28 +370,93 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
   HIPCHK(hipMemsetAsync(d_sum, 0, n_pairs * sizeof(double), e->st));
   HIPCHK(hipMemsetAsync(d_cnt, 0, n_pairs * sizeof(unsigned long long), e->st));
 
-  HIPCHK(hipEventRecord(e->ev[1], e->st));
-  switch (e->kernel) {
-    case NGD_KERNEL_STREAM:
+  auto accumulate = [&](const uint32_t *w, uint64_t sites_eff, uint32_t n_ks, uint64_t per_slice, uint64_t kg_lim,
+                        double *slab) {
+    switch (e->kernel) {
+      case NGD_KERNEL_MFMA:
+        if (env_u64("NGD_MFMA_VARIANT", 0) == 2)
+          ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
+        else
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
+        break;
+      default:
+        ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
+                            e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
+    }
+  };
+
+  // Bootstrap by per-block partial sums: every site's contribution is independent of
+  // the replicate, so sum_rep = SUM_b multiplicity_rep[b] * S_b with S_b the block's partial sum.
+  // One extra accumulation pass fills S_b; each replicate is then a weighted slab reduction.
+  // MFMA slices are whole k-groups of 4, so blocks must be multiples of 4 sites there.
+  bool partials = false;
+  uint32_t launches = 1;
+  if (block_map && e->kernel != NGD_KERNEL_STREAM && env_u64("NGD_BOOT_PARTIALS", 1)) {
+    const bool mfma = e->kernel == NGD_KERNEL_MFMA;
+    if (!mfma || block_size % 4 == 0) {
+      // split large blocks so that there are enough workgroups; slices of one block share its weight
+      const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
+      const uint32_t tiles_n = mfma ? e->n_tiles : e->n_tiles16;
+      uint64_t sub = 1;
+      const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
+      while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)
+        sub *= 2;
+      uint64_t nks = n_blocks * sub;
+      if (mfma) nks = (nks + 7) / 8 * 8;  // the XCD deal of accum_mfma.hip
+      const uint64_t elems = nks * (uint64_t)g.n_pad * g.n_pad;
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)(total_b / 4));
+      const bool cached = e->boot_B == block_size && e->boot_blocks == n_blocks;
+      if (cached || (elems * 8 <= budget && (elems <= e->slab_boot_elems || elems * 8 + (1ull << 30) <= free_b))) {
+        partials = true;
+        if (!cached) {
+          e->boot_B = 0;
+          if (elems > e->slab_boot_elems) {
+            if (e->slab_boot) { HIPCHK(hipFree(e->slab_boot)); e->dev_bytes -= e->slab_boot_elems * 8; }
+            if (e->d_wslice) { HIPCHK(hipFree(e->d_wslice)); e->dev_bytes -= e->slab_boot_elems / ((uint64_t)g.n_pad * g.n_pad) * 8; }
+            e->slab_boot = nullptr; e->d_wslice = nullptr; e->slab_boot_elems = 0;
+            int rc = dev_alloc(e, &e->slab_boot, elems, false);
+            if (rc) return rc;
+            rc = dev_alloc(e, &e->d_wslice, nks, false);
+            if (rc) return rc;
+            e->slab_boot_elems = elems;
+          }
+          e->boot_nks = (uint32_t)nks;
+          e->boot_sub = (uint32_t)sub;
+          e->boot_per_slice = unit / sub;
+          HIPCHK(hipEventRecord(e->ev[1], e->st));
+          accumulate(nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipEventRecord(e->ev[2], e->st));
+          e->boot_B = block_size;
+          e->boot_blocks = n_blocks;
+        } else {
+          HIPCHK(hipEventRecord(e->ev[1], e->st));
+          HIPCHK(hipEventRecord(e->ev[2], e->st));
+          launches = 0;
+        }
+        std::vector<double> wslice(e->boot_nks, 0.0);
+        for (uint64_t b = 0; b < n_blocks; b++)
+          for (uint32_t q = 0; q < e->boot_sub; q++) wslice[b * e->boot_sub + q] = (double)mult[b];
+        HIPCHK(hipMemcpyAsync(e->d_wslice, wslice.data(), wslice.size() * 8, hipMemcpyHostToDevice, e->st));
+        ngd_launch_reduce_w(e->st, g, e->slab_boot, e->boot_nks, e->d_wslice, e->d_tiles, e->n_tiles, d_sum);
+        HIPCHK(hipStreamSynchronize(e->st));  // wslice is a host temporary
+      }
+    }
+  }
+
+  if (!partials) {
+    HIPCHK(hipEventRecord(e->ev[1], e->st));
+    if (e->kernel == NGD_KERNEL_STREAM)
       ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
                               e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
-      break;
-    case NGD_KERNEL_MFMA:
-      if (env_u64("NGD_MFMA_VARIANT", 0) == 2)
-        ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
-                                  g.n_kg, e->slab);
-      else
-        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, ws, e->d_tiles, e->n_tiles, e->n_ks, e->per_slice,
-                              g.n_kg, e->slab);
-      break;
-    default:
-      ngd_launch_accum_em(e->st, g, e->PA, ws, n_eff, e->sc, e->cfg.pairwise_del,
-                          e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, e->n_ks,
-                          e->per_slice, e->slab);
+    else
+      accumulate(ws, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[2], e->st));
+    if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e->ev[2], e->st));
-  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
@@ -404,7 +475,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
   HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); t.ms_reduce = ms;
   HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); t.ms_count = ms;
   t.pair_sites = e->n_owned_pairs * n_eff;
-  t.launches = 1;
+  t.launches = launches;
   return NGD_OK;
 }
 
@@ -422,6 +493,13 @@ int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_
   const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
   if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));
   if (cnt) HIPCHK(hipMemcpy(cnt, e->d_cnt, n_pairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return NGD_OK;
+}
+
+int ngd_drop_caches(ngd_engine *e) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_drop_caches: null engine");
+  e->boot_B = 0;
+  e->boot_blocks = 0;
   return NGD_OK;
 }
 

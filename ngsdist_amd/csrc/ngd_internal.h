@@ -94,6 +94,8 @@ void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, co
 // reduce.hip : deterministic slab reduction + valid-site counting
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
                        const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
+void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
+                         const double *d_w, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
                       const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles16,
                       uint32_t n_tiles16, unsigned long long *d_cnt);

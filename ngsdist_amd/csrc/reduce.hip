@@ -22,6 +22,27 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
   d_sum[ngd_pair_idx(n_ind, i, j)] = s;
 }
 
+// Bootstrap replicate from per-block partial sums: sum = SUM_slice w[slice] * slab[slice], slices in
+// ascending order (deterministic).  w = multiplicity of the slice's block in this replicate
+// (reference rnd_map_data, ngsDist.cpp:416-437: a block drawn m times is visited m times).
+__global__ __launch_bounds__(128) void k_reduce_w(const double *__restrict__ slab, uint32_t n_ks,
+                                                   const double *__restrict__ w,
+                                                   const ngd_tile *__restrict__ tiles, uint32_t n_pad,
+                                                   uint64_t n_ind, double *__restrict__ d_sum) {
+  const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
+  const uint32_t i = tiles[tile].ti * NGD_TILE + row;
+  const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
+  if (!(i < j && j < n_ind)) return;
+  const uint64_t plane = (uint64_t)n_pad * n_pad;
+  const double *p = slab + (uint64_t)i * n_pad + j;
+  double s = 0;
+  for (uint32_t ks = 0; ks < n_ks; ks++) {
+    const double wk = w[ks];  // uniform across the workgroup
+    if (wk != 0.0) s += wk * p[ks * plane];
+  }
+  d_sum[ngd_pair_idx(n_ind, i, j)] = s;
+}
+
 __global__ __launch_bounds__(128) void k_fill_cnt(const ngd_tile *__restrict__ tiles, uint64_t n_ind,
                                                    unsigned long long value,
                                                    unsigned long long *__restrict__ d_cnt) {
@@ -79,6 +100,13 @@ void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, ui
                        const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
   if (!n_tiles) return;
   hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, d_tiles, g.n_pad,
+                     g.n_ind, d_sum);
+}
+
+void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
+                         const double *d_w, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
+  if (!n_tiles) return;
+  hipLaunchKernelGGL(k_reduce_w, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, d_w, d_tiles, g.n_pad,
                      g.n_ind, d_sum);
 }
 

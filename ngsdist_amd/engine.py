@@ -126,6 +126,10 @@ class Engine:
         ptr, nb, bs, keep = self._map_args(block_map, block_size)
         _check(self._L.ngd_run_device(self._h, ptr, nb, bs, C.c_void_p(d_sum_ptr), C.c_void_p(d_cnt_ptr)))
 
+    def drop_caches(self):
+        """forget the bootstrap block partial sums (benchmarks: charge them to every step)"""
+        _check(self._L.ngd_drop_caches(self._h))
+
     def timing(self):
         t = _lib.NgdTiming()
         _check(self._L.ngd_last_timing(self._h, C.byref(t)))

@@ -148,6 +148,37 @@ def test_bootstrap_replicates(kernel, block_size):
         assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
+@pytest.mark.parametrize("kernel,block_size", [("mfma", 8), ("mfma", 100), ("em_fast", 5), ("em_faithful", 12)])
+def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkeypatch):
+    """Replicates served from per-block partial sums (default) vs. one weighted accumulation
+    pass per replicate (NGD_BOOT_PARTIALS=0): same counts, sums within rounding, both within
+    tolerance of the oracle; changing the block size re-derives the partial sums."""
+    n_ind, n_sites = 40, 2003
+    indep = kernel == "mfma"
+    p = O.synth_indmajor(17, n_ind, n_sites, miss_frac=0.15)
+    rng = N().Taus(4242)
+    with N().Engine(n_ind, n_sites, pairwise_del=True, indep_geno=indep, kernel=kernel) as e:
+        e.upload_ind_major(p).commit()
+        for B in (block_size, 2 * block_size):
+            n_eff = n_sites - n_sites % B
+            for rep in range(2):
+                bm = rng.block_map(n_eff // B)
+                monkeypatch.setenv("NGD_BOOT_PARTIALS", "1")
+                s1, c1 = e.run(bm, B)
+                t1 = e.timing()
+                monkeypatch.setenv("NGD_BOOT_PARTIALS", "0")
+                s0, c0 = e.run(bm, B)
+                so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, site_src=O.boot_site_src(bm, B),
+                                     n_sites=n_eff, n_threads=8)
+                assert np.array_equal(c1, co) and np.array_equal(c0, co)
+                assert rel_err(s1, so) < RTOL and rel_err(s0, so) < RTOL
+                assert t1["launches"] == (1 if rep == 0 else 0)  # second replicate re-uses the partial sums
+        monkeypatch.setenv("NGD_BOOT_PARTIALS", "1")
+        e.drop_caches()
+        e.run(bm, B)
+        assert e.timing()["launches"] == 1
+
+
 def test_heavy_multiplicity_counts():
     """all blocks map to block 0 -> multiplicity n_blocks on a few sites (bit-plane path)."""
     n_ind, n_sites, B = 5, 640, 2
