@@ -76,30 +76,34 @@ __device__ __forceinline__ double site_faithful(const double *g1, const double *
   return acc;
 }
 
+// fast form.  a_k = g1[x]*g2[y] is rank one, so a_k^t = g1[x]^t * g2[y]^t and
+//   S_t = SUM_k a_k^t = (SUM_x g1[x]^t) * (SUM_y g2[y]^t) = A_t * B_t :
+// six running powers instead of nine, and the score-weighted sum at the end is
+// u1' * score * u2 / (A_T * B_T) with u = g^T.
 __device__ __forceinline__ double site_fast(const double *g1, const double *g2, const ngd_score &sc,
                                             double acc, double w) {
-  const double E = 1.0010005001667084;  // exp(0.001)
-  double a[9], u[9];
-#pragma unroll
-  for (int x = 0; x < 3; x++)
-#pragma unroll
-    for (int y = 0; y < 3; y++) a[3 * x + y] = g1[x] * g2[y];
-  double Sm = 9.0, Sc = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) { u[k] = a[k]; Sc += a[k]; }
+  const double E = 0x1.0041919b7ee34p+0;  // exp(0.001), the tolerance of ngsDist.cpp:349
+  double u1[3] = {g1[0], g1[1], g1[2]}, u2[3] = {g2[0], g2[1], g2[2]};
+  double Sm = 9.0;                                                     // S_0 (uniform start, 9 cells)
+  double Sc = ((u1[0] + u1[1]) + u1[2]) * ((u2[0] + u2[1]) + u2[2]);   // S_1
   for (int t = 1;; t++) {
-    double un[9], Sn = 0;
+    double n1[3], n2[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) { un[k] = u[k] * a[k]; Sn += un[k]; }
-    bool stop = (Sn * Sm < E * (Sc * Sc)) || t == MAX_ITER;
+    for (int x = 0; x < 3; x++) { n1[x] = u1[x] * g1[x]; n2[x] = u2[x] * g2[x]; }
+    const double Sn = ((n1[0] + n1[1]) + n1[2]) * ((n2[0] + n2[1]) + n2[2]);  // S_{t+1}
+    // |lik_t - lik_{t-1}| < tole  <=>  S_{t+1} S_{t-1} < e^tole S_t^2   (lik is non-decreasing)
+    const bool stop = (Sn * Sm < E * (Sc * Sc)) || t == MAX_ITER;
     if (stop) break;
 #pragma unroll
-    for (int k = 0; k < 9; k++) u[k] = un[k];
+    for (int x = 0; x < 3; x++) { u1[x] = n1[x]; u2[x] = n2[x]; }
     Sm = Sc; Sc = Sn;
   }
   double c = 0;
 #pragma unroll
-  for (int k = 0; k < 9; k++) c += sc.v[k] * u[k];
+  for (int x = 0; x < 3; x++) {
+    const double q = (sc.v[3 * x] * u2[0] + sc.v[3 * x + 1] * u2[1]) + sc.v[3 * x + 2] * u2[2];
+    c += u1[x] * q;
+  }
   return acc + (c / Sc) * w;
 }
 
