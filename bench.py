@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
+    ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,11 +70,16 @@ def main():
             raise SystemExit("bench.py: --gpus %d needs a torch.distributed.run launch" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the product path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W = dict(WORKLOADS[args.workload])
     if args.n_sites:
@@ -109,11 +117,16 @@ def main():
                 red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
                 if t["launches"]:  # a replicate served from block partial sums launches no accumulation
                     acc_ms.append(t["ms_accum"]); pair_sites.append(t["pair_sites"])
-            merge_shards(d_sum, d_cnt, dst=0)  # one RCCL collective per array; disjoint shards
+            if args.backend == "nccl":
+                merge_shards(d_sum, d_cnt, dst=0)  # one RCCL collective per array; disjoint shards
+                if rank == 0:
+                    h_sum.copy_(d_sum, non_blocking=True)
+                    h_cnt.copy_(d_cnt, non_blocking=True)
+                    torch.cuda.synchronize()
+            else:  # rehearsal: merge on the host over gloo
+                h_sum.copy_(d_sum); h_cnt.copy_(d_cnt)
+                merge_shards(h_sum, h_cnt, dst=0)
             if rank == 0:
-                h_sum.copy_(d_sum, non_blocking=True)
-                h_cnt.copy_(d_cnt, non_blocking=True)
-                torch.cuda.synchronize()
                 with np.errstate(all="ignore"):
                     last["dist"] = N.finish(h_sum.numpy(), h_cnt.numpy().view(np.uint64), 0, W["evol_model"])
 
@@ -121,6 +134,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def allred(x, op):
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step(False)
@@ -131,16 +149,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = allred(dt, dist.ReduceOp.MAX)
         # per-rank accumulation-kernel time: report the slowest rank's mean
-        am = torch.tensor([float(np.mean(acc_ms))], dtype=torch.float64, device=dev)
-        dist.all_reduce(am, op=dist.ReduceOp.MAX)
-        acc_mean_ms = float(am.item())
-        ps = torch.tensor([float(np.mean(pair_sites))], dtype=torch.float64, device=dev)
-        dist.all_reduce(ps, op=dist.ReduceOp.SUM)
-        pair_sites_per_launch_all = float(ps.item())
+        acc_mean_ms = allred(float(np.mean(acc_ms)) if acc_ms else 0.0, dist.ReduceOp.MAX)
+        pair_sites_per_launch_all = allred(float(np.mean(pair_sites)) if pair_sites else 0.0, dist.ReduceOp.SUM)
     else:
         acc_mean_ms = float(np.mean(acc_ms))
         pair_sites_per_launch_all = float(np.mean(pair_sites))

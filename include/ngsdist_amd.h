@@ -40,6 +40,7 @@ extern "C" {
 #define NGD_E_HIP (-3)      /* a HIP runtime call failed                   */
 #define NGD_E_NOMEM (-4)    /* host or device allocation failed            */
 #define NGD_E_MODEL (-5)    /* evolutionary model 3..6 (reference: error())*/
+#define NGD_E_NAN (-6)      /* "NaN found! Is the file format correct?" (read_data.cpp:42-45) */
 
 /* which kernel serves the per-pair accumulation */
 #define NGD_KERNEL_AUTO 0
@@ -98,6 +99,28 @@ void ngd_destroy(ngd_engine *e);
 int ngd_upload_sites(ngd_engine *e, const double *p, uint64_t s0, uint64_t n);
 int ngd_upload_ind_major(ngd_engine *e, const double *p);
 int ngd_commit(ngd_engine *e);
+
+/* Raw input: the doubles of a BINARY GL file exactly as stored (read_data.cpp:28-31,
+ * [site][individual][3]); the engine performs the reference's kernel-input construction
+ * on the device -- log unless in_logscale, normalisation (post_prob), the NaN check of
+ * read_data.cpp:37-45, then call_geno and exp of ngsDist.cpp:165-174 -- instead of the
+ * host.  Device log/exp agree with glibc's to the last ulp or so: use the host path
+ * (ngd_upload_sites) where called genotypes must be decided bit-for-bit as on the CPU.
+ *
+ * Zero-copy pipeline: ngd_stage_acquire() lends one of the engine's pinned host buffers
+ * (*capacity_sites sites of n_ind*3 doubles); the caller reads the file straight into it
+ * and calls ngd_stage_submit(), which returns at once while the copy and the kernel run;
+ * the next acquire hands out the other buffer.  ngd_upload_raw_sites() is the blocking
+ * convenience form.  NGD_E_NAN is reported by ngd_commit() at the latest. */
+typedef struct ngd_prep {
+  int32_t in_logscale; /* --log_scale                           */
+  int32_t call_geno;   /* --call_geno (or -N / -C)              */
+  double N_thresh;     /* --N_thresh                            */
+  double call_thresh;  /* --call_thresh                         */
+} ngd_prep;
+int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites);
+int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *prep);
+int ngd_upload_raw_sites(ngd_engine *e, const double *raw, uint64_t s0, uint64_t n, const ngd_prep *prep);
 
 /* Test/bench input: fills the engine with this repository's counter-based
  * synthetic data set (bit-identical to oracle ngo_synth_one) on

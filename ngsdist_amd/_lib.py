@@ -27,6 +27,11 @@ class NgdConfig(C.Structure):
     ]
 
 
+class NgdPrep(C.Structure):
+    _fields_ = [("in_logscale", C.c_int32), ("call_geno", C.c_int32), ("N_thresh", C.c_double),
+                ("call_thresh", C.c_double)]
+
+
 class NgdTiming(C.Structure):
     _fields_ = [
         ("ms_total", C.c_double),
@@ -41,7 +46,8 @@ class NgdTiming(C.Structure):
 # every symbol include/ngsdist_amd.h declares (tests/test_abi.py checks the header against this)
 EXPORTS = [
     "ngd_last_error", "ngd_abi_version", "ngd_device_count", "ngd_create", "ngd_destroy",
-    "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_synth_fill", "ngd_run",
+    "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
+    "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_run",
     "ngd_run_device", "ngd_drop_caches", "ngd_last_timing", "ngd_finish", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_shard_of_pair",
 ]
@@ -80,6 +86,9 @@ def load():
     L.ngd_upload_sites.argtypes = [vp, dp, u64, u64]
     L.ngd_upload_ind_major.argtypes = [vp, dp]
     L.ngd_commit.argtypes = [vp]
+    L.ngd_stage_acquire.argtypes = [vp, C.POINTER(dp), u64p]
+    L.ngd_stage_submit.argtypes = [vp, u64, u64, C.POINTER(NgdPrep)]
+    L.ngd_upload_raw_sites.argtypes = [vp, dp, u64, u64, C.POINTER(NgdPrep)]
     L.ngd_synth_fill.argtypes = [vp, u64, C.c_double]
     L.ngd_run.argtypes = [vp, u64p, u64, u64, dp, u64p]
     L.ngd_run_device.argtypes = [vp, u64p, u64, u64, vp, vp]

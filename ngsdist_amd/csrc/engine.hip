@@ -60,6 +60,12 @@ struct ngd_engine {
   uint32_t boot_nks = 0, boot_sub = 0;
   double *staging = nullptr;
   uint64_t staging_sites = 0;
+  // raw-input pipeline: two pinned host buffers + two device buffers, alternating
+  double *pin[2] = {nullptr, nullptr}, *draw[2] = {nullptr, nullptr};
+  hipEvent_t pin_free[2] = {nullptr, nullptr};
+  int pin_cur = 0, pin_lent = -1;
+  uint64_t pin_sites = 0;
+  int *d_nan = nullptr;
   bool committed = false;
   uint64_t dev_bytes = 0;
   ngd_timing timing{};
@@ -104,6 +110,12 @@ void ngd_destroy(ngd_engine *e) {
                   e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  for (int b = 0; b < 2; b++) {
+    if (e->pin[b]) hipHostFree(e->pin[b]);
+    if (e->draw[b]) hipFree(e->draw[b]);
+    if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
+  }
+  if (e->d_nan) hipFree(e->d_nan);
   for (auto &v : e->ev)
     if (v) hipEventDestroy(v);
   if (e->st) hipStreamDestroy(e->st);
@@ -305,10 +317,82 @@ int ngd_upload_ind_major(ngd_engine *e, const double *p) {
   return upload_common(e, p, 1, 0, e->g.n_sites);
 }
 
+static int stage_init(ngd_engine *e) {
+  if (e->pin[0]) return NGD_OK;
+  e->pin_sites = std::max<uint64_t>(1, std::min<uint64_t>(e->g.n_sites, (128ull << 20) / (e->g.n_ind * 24)));
+  const uint64_t bytes = e->pin_sites * e->g.n_ind * 24;
+  for (int b = 0; b < 2; b++) {
+    HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
+    int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
+    if (rc) return rc;
+    HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
+  }
+  int rc = dev_alloc(e, &e->d_nan, 1, true);
+  return rc;
+}
+
+int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites) {
+  if (!e || !host_buf || !capacity_sites) return fail(NGD_E_INVALID, "ngd_stage_acquire: null argument");
+  if (e->committed) return fail(NGD_E_INVALID, "ngd_stage_acquire: data set already committed");
+  HIPCHK(hipSetDevice(e->device));
+  int rc = stage_init(e);
+  if (rc) return rc;
+  const int b = e->pin_cur;
+  HIPCHK(hipEventSynchronize(e->pin_free[b]));  // the copy out of this buffer (two submits ago) is done
+  e->pin_lent = b;
+  *host_buf = e->pin[b];
+  *capacity_sites = e->pin_sites;
+  return NGD_OK;
+}
+
+int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *prep) {
+  if (!e || !prep) return fail(NGD_E_INVALID, "ngd_stage_submit: null argument");
+  if (e->pin_lent < 0) return fail(NGD_E_INVALID, "ngd_stage_submit: no buffer acquired");
+  if (prep->call_geno && prep->N_thresh > prep->call_thresh)  // call_geno(), gen_func.cpp:887-888
+    return fail(NGD_E_INVALID, "missing data threshold must be smaller than calling genotype threshold!");
+  if (n > e->pin_sites || s0 + n > e->g.n_sites || s0 + n < s0)
+    return fail(NGD_E_INVALID, "ngd_stage_submit: site range out of bounds");
+  HIPCHK(hipSetDevice(e->device));
+  const int b = e->pin_lent;
+  HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipEventRecord(e->pin_free[b], e->st));
+  ngd_launch_prep_layout(e->st, e->g, e->draw[b], s0, n, prep->in_logscale, prep->call_geno, prep->N_thresh,
+                         prep->call_thresh, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask, e->d_nan);
+  HIPCHK(hipGetLastError());
+  e->pin_lent = -1;
+  e->pin_cur = b ^ 1;
+  return NGD_OK;
+}
+
+int ngd_upload_raw_sites(ngd_engine *e, const double *raw, uint64_t s0, uint64_t n, const ngd_prep *prep) {
+  if (!e || !raw || !prep) return fail(NGD_E_INVALID, "ngd_upload_raw_sites: null argument");
+  for (uint64_t done = 0; done < n;) {
+    double *buf;
+    uint64_t cap;
+    int rc = ngd_stage_acquire(e, &buf, &cap);
+    if (rc) return rc;
+    const uint64_t c = std::min(cap, n - done);
+    memcpy(buf, raw + done * e->g.n_ind * 3, c * e->g.n_ind * 24);
+    rc = ngd_stage_submit(e, s0 + done, c, prep);
+    if (rc) return rc;
+    done += c;
+  }
+  return NGD_OK;
+}
+
 int ngd_commit(ngd_engine *e) {
   if (!e) return fail(NGD_E_INVALID, "ngd_commit: null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->st));
+  if (e->d_nan) {
+    int flag = 0;
+    HIPCHK(hipMemcpy(&flag, e->d_nan, sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < 2; b++) {  // the pipeline is over: give its buffers back
+      if (e->pin[b]) { HIPCHK(hipHostFree(e->pin[b])); e->pin[b] = nullptr; }
+      if (e->draw[b]) { HIPCHK(hipFree(e->draw[b])); e->draw[b] = nullptr; e->dev_bytes -= e->pin_sites * e->g.n_ind * 24; }
+    }
+    if (flag) return fail(NGD_E_NAN, "NaN found! Is the file format correct?");
+  }
   if (e->staging) {  // upload is over: give the staging buffer back
     HIPCHK(hipFree(e->staging));
     e->dev_bytes -= e->staging_sites * e->g.n_ind * 24;

@@ -20,13 +20,16 @@
 //  * a file name without a '.' is treated as binary instead of dereferencing
 //    NULL (ngsDist.cpp:82);
 //  * extra options: --n_gpus N (pair tiles dealt over N devices of this node),
-//    --device D (first device), --kernel auto|stream|mfma|em_fast|em_faithful.
+//    --device D (first device), --kernel auto|stream|mfma|em_fast|em_faithful,
+//    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
+//    device, except host when genotypes are called so that calls are decided by glibc).
 #include <getopt.h>
 #include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -62,6 +65,7 @@ struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
   unsigned n_threads = 1, verbose = 1, seed = 0;
   // engine placement (not in the reference)
   int n_gpus = 1, device = 0, kernel = NGD_KERNEL_AUTO;
+  int prep = 0;  // 0 auto (device unless genotypes are called), 1 host, 2 device
 };
 
 // error(), gen_func.cpp:12-18: message, perror, exit(-1)
@@ -108,6 +112,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
                                  {"n_gpus", required_argument, nullptr, 1001},
                                  {"device", required_argument, nullptr, 1002},
                                  {"kernel", required_argument, nullptr, 1003},
+                                 {"prep", required_argument, nullptr, 1004},
                                  {nullptr, 0, nullptr, 0}};
   p.seed = (unsigned)time(nullptr);  // parse_args.cpp:35
   int c;
@@ -145,6 +150,12 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
         else if (!strcmp(optarg, "em_fast")) p.kernel = NGD_KERNEL_EM_FAST;
         else if (!strcmp(optarg, "em_faithful")) p.kernel = NGD_KERNEL_EM_FAITHFUL;
         else die(__FUNCTION__, "unknown --kernel");
+        break;
+      case 1004:
+        if (!strcmp(optarg, "auto")) p.prep = 0;
+        else if (!strcmp(optarg, "host")) p.prep = 1;
+        else if (!strcmp(optarg, "device")) p.prep = 2;
+        else die(__FUNCTION__, "unknown --prep");
         break;
       default: exit(-1);
     }
@@ -305,7 +316,13 @@ struct Engines {
   void upload_sites(const double *p, uint64_t s0, uint64_t n) {
     for (auto *h : e) { int rc = ngd_upload_sites(h, p, s0, n); if (rc) die_engine("upload", rc); }
   }
-  void commit() { for (auto *h : e) { int rc = ngd_commit(h); if (rc) die_engine("commit", rc); } }
+  void commit() {
+    for (auto *h : e) {
+      int rc = ngd_commit(h);
+      if (rc == NGD_E_NAN) die("read_geno", "NaN found! Is the file format correct?");
+      if (rc) die_engine("commit", rc);
+    }
+  }
   ~Engines() { for (auto *h : e) ngd_destroy(h); }
 };
 
@@ -318,20 +335,41 @@ static void load_and_upload(const Pars &p, Engines &eng) {
   std::vector<double> buf(chunk * n_ind * 3);
   bool in_logscale = p.in_logscale;
 
-  if (p.in_bin) {
+  const bool device_prep = p.in_bin && (p.prep == 2 || (p.prep == 0 && !p.call_geno));
+  auto read_exact = [&](double *dst, uint64_t bytes) {
+    uint64_t got = 0;
+    while (got < bytes) {
+      int r = gzread(fh, (char *)dst + got, (unsigned)std::min<uint64_t>(bytes - got, 1u << 30));
+      if (r <= 0) break;
+      got += (uint64_t)r;
+    }
+    if (got != bytes) {
+      if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+      die("read_geno", "cannot read binary GENO file. Check GENO file and number of sites!");
+    }
+  };
+  if (p.in_bin && device_prep) {
+    // read straight into the engine's pinned buffers; copy + preparation kernel overlap the next read
+    ngd_prep pr;
+    pr.in_logscale = in_logscale; pr.call_geno = p.call_geno; pr.N_thresh = p.N_thresh; pr.call_thresh = p.call_thresh;
+    for (uint64_t s0 = 0; s0 < n_sites;) {
+      double *pin; uint64_t cap;
+      int rc = ngd_stage_acquire(eng.e[0], &pin, &cap);
+      if (rc) die_engine("ngd_stage_acquire", rc);
+      const uint64_t n = std::min(cap, n_sites - s0);
+      read_exact(pin, n * n_ind * 24);
+      for (size_t r = 1; r < eng.e.size(); r++) {
+        rc = ngd_upload_raw_sites(eng.e[r], pin, s0, n, &pr);
+        if (rc) die_engine("ngd_upload_raw_sites", rc);
+      }
+      rc = ngd_stage_submit(eng.e[0], s0, n, &pr);
+      if (rc) die_engine("ngd_stage_submit", rc);
+      s0 += n;
+    }
+  } else if (p.in_bin) {
     for (uint64_t s0 = 0; s0 < n_sites; s0 += chunk) {
       const uint64_t n = std::min(chunk, n_sites - s0);
-      const uint64_t bytes = n * n_ind * 24;
-      uint64_t got = 0;
-      while (got < bytes) {
-        int r = gzread(fh, (char *)buf.data() + got, (unsigned)std::min<uint64_t>(bytes - got, 1u << 30));
-        if (r <= 0) break;
-        got += (uint64_t)r;
-      }
-      if (got != bytes) {
-        if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
-        die("read_geno", "cannot read binary GENO file. Check GENO file and number of sites!");
-      }
+      read_exact(buf.data(), n * n_ind * 24);
       std::atomic<bool> bad{false};
       parallel_for(p.n_threads, n * n_ind, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t e = lo; e < hi; e++)
@@ -497,7 +535,13 @@ int main(int argc, char **argv) {
   }
 
   if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
+  const auto t_load0 = std::chrono::steady_clock::now();
   load_and_upload(p, eng);
+  const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
+  if (p.verbose >= 2)
+    fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident per device)\n", t_load,
+            (double)p.n_ind * p.n_sites * 24 / 1e9);
+  double t_compute = 0;
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];
@@ -534,6 +578,7 @@ int main(int argc, char **argv) {
                     b * p.boot_block_size + s, block_map[b], block_map[b] * p.boot_block_size + s);
     }
     if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
+    const auto t_c0 = std::chrono::steady_clock::now();
     if (eng.e.size() == 1) {
       int rc = ngd_run(eng.e[0], bm, n_blocks, p.boot_block_size, sum.data(), cnt.data());
       if (rc) die_engine("ngd_run", rc);
@@ -561,6 +606,7 @@ int main(int argc, char **argv) {
     }
     int rc = ngd_finish(sum.data(), cnt.data(), n_comb, p.tot_sites, p.evol_model, dist.data());
     if (rc) die("gen_dist", "invalid evolutionary model specified!");
+    t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
     uint64_t k = 0;
     for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
       for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
@@ -580,6 +626,9 @@ int main(int argc, char **argv) {
     }
   }
   fclose(out_fh);
+  if (p.verbose >= 2)
+    fprintf(stderr, "> distances: %.3f s for %lu matri%s of %lu pairs\n", t_compute, p.n_boot_rep + 1,
+            p.n_boot_rep ? "ces" : "x", n_comb);
   if (p.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
   if (p.verbose >= 1) fprintf(stderr, "Done!\n");
   return 0;

@@ -2,8 +2,11 @@
 // libm / integer arithmetic to reproduce the reference's printed cells exactly:
 // the tail of gen_dist() (reference ngsDist.cpp:372-401) and the bootstrap block
 // draw (ngsDist.cpp:416-423 over gsl_rng_taus, seeded at :179-180).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <thread>
+#include <vector>
 
 #include "../../include/ngsdist_amd.h"
 
@@ -23,6 +26,21 @@ inline uint32_t taus_get(uint32_t st[3]) {
   return st[0] ^ st[1] ^ st[2];
 }
 }  // namespace
+
+static void finish_range(const double *sum, const uint64_t *cnt, uint64_t lo, uint64_t hi, uint64_t tot_sites,
+                         uint64_t evol_model, double *dist) {
+  for (uint64_t k = lo; k < hi; k++) {
+    uint64_t c = cnt[k];
+    if (tot_sites > 0) c = tot_sites;
+    double d = sum[k];
+    d /= (double)c;
+    if (evol_model == 1)
+      d = -log(1 - d);
+    else if (evol_model == 2)
+      d = -log(1 - (d * 4 / 3)) * 3 / 4;
+    dist[k] = d;
+  }
+}
 
 extern "C" {
 
@@ -60,16 +78,20 @@ int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_
                uint64_t evol_model, double *dist) {
   if (evol_model > 2) return NGD_E_MODEL;  // reference: error("... model not yet supported")
   if (!sum || !cnt || !dist) return NGD_E_INVALID;
-  for (uint64_t k = 0; k < n_pairs; k++) {
-    uint64_t c = cnt[k];
-    if (tot_sites > 0) c = tot_sites;
-    double d = sum[k];
-    d /= (double)c;
-    if (evol_model == 1)
-      d = -log(1 - d);
-    else if (evol_model == 2)
-      d = -log(1 - (d * 4 / 3)) * 3 / 4;
-    dist[k] = d;
+  // per-cell and order-free, so threads change nothing but the wall time
+  unsigned nt = 1;
+  if (n_pairs >= (1u << 16)) nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt <= 1) {
+    finish_range(sum, cnt, 0, n_pairs, tot_sites, evol_model, dist);
+  } else {
+    std::vector<std::thread> th;
+    const uint64_t per = (n_pairs + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+      const uint64_t lo = t * per, hi = std::min(n_pairs, lo + per);
+      if (lo >= hi) break;
+      th.emplace_back(finish_range, sum, cnt, lo, hi, tot_sites, evol_model, dist);
+    }
+    for (auto &t : th) t.join();
   }
   return NGD_OK;
 }

@@ -45,6 +45,60 @@ __global__ void k_layout(ngd_geom g, const double *__restrict__ raw, int raw_ind
   emit(g, sc, pairwise_del, s0 + sl, i, src[0], src[1], src[2], PA, QB, PI, mask);
 }
 
+// K0: the kernel-input construction of the reference for ONE (individual, site) of
+// a binary GL file, on the device: read_data.cpp:37-45 (log unless --log_scale, -inf
+// clamp of conv_space gen_func.cpp:123-130, post_prob :920-932 over logsum :135-151,
+// NaN check) then ngsDist.cpp:165-174 (call_geno gen_func.cpp:886-914, exp).
+// Same operation order as the host; log/exp are the device's (<= 1 ulp of glibc's).
+__global__ void k_prep_layout(ngd_geom g, const double *__restrict__ raw, uint64_t s0, uint64_t n_chunk,
+                              int in_logscale, int call_geno, double N_thresh, double call_thresh,
+                              ngd_score sc, int pairwise_del, double *PA, double *QB, double *PI,
+                              unsigned long long *mask, int *nan_flag) {
+  uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_chunk * g.n_ind) return;
+  uint64_t sl = e / g.n_ind;
+  uint32_t i = (uint32_t)(e - sl * g.n_ind);
+  double l[3] = {raw[3 * e], raw[3 * e + 1], raw[3 * e + 2]};
+  if (!in_logscale) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      l[c] = log(l[c]);
+      if (l[c] == -INFINITY) l[c] = -1e15;  // INF, gen_func.hpp:15
+    }
+  }
+  {  // post_prob / logsum
+    double M = l[0];
+    M = (l[1] >= M ? l[1] : M);
+    M = (l[2] >= M ? l[2] : M);
+    double norm;
+    if (M == -INFINITY) {
+      norm = -INFINITY;
+    } else {
+      double sum = 0;
+      sum += exp(l[0] - M); sum += exp(l[1] - M); sum += exp(l[2] - M);
+      norm = log(sum) + M;
+    }
+    l[0] -= norm; l[1] -= norm; l[2] -= norm;
+  }
+  if (l[0] != l[0] || l[1] != l[1] || l[2] != l[2]) atomicOr(nan_flag, 1);
+  if (call_geno) {
+    int max_pos = 0, min_pos = 0;
+    double mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (l[c] > mx) { mx = l[c]; max_pos = c; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (l[c] < mn) { mn = l[c]; min_pos = c; }
+    double max_pp = exp(l[max_pos]);
+    if (l[min_pos] == l[max_pos]) max_pp = -1;
+    if (max_pp < N_thresh) { const double t = log((double)1 / 3); l[0] = l[1] = l[2] = t; }
+    if (max_pp >= call_thresh) {
+      l[0] = l[1] = l[2] = -1e15;
+      l[max_pos] = 0.0;  // log(1)
+    }
+  }
+  emit(g, sc, pairwise_del, s0 + sl, i, exp(l[0]), exp(l[1]), exp(l[2]), PA, QB, PI, mask);
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -111,6 +165,16 @@ void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int
   if (!n) return;
   hipLaunchKernelGGL(k_layout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, raw,
                      raw_ind_major, s0, n_chunk, score, pairwise_del, PA, QB, PI, mask);
+}
+
+void ngd_launch_prep_layout(hipStream_t st, const ngd_geom &g, const double *raw, uint64_t s0, uint64_t n_chunk,
+                            int in_logscale, int call_geno, double N_thresh, double call_thresh,
+                            const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
+                            unsigned long long *mask, int *nan_flag) {
+  uint64_t n = n_chunk * g.n_ind;
+  if (!n) return;
+  hipLaunchKernelGGL(k_prep_layout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, raw, s0, n_chunk,
+                     in_logscale, call_geno, N_thresh, call_thresh, score, pairwise_del, PA, QB, PI, mask, nan_flag);
 }
 
 void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,

@@ -62,6 +62,10 @@ struct ngd_tile {
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
                        uint64_t s0, uint64_t n_sites_chunk, const ngd_score &score, int pairwise_del,
                        double *PA, double *QB, double *PI, unsigned long long *mask);
+void ngd_launch_prep_layout(hipStream_t st, const ngd_geom &g, const double *raw, uint64_t s0, uint64_t n_chunk,
+                            int in_logscale, int call_geno, double N_thresh, double call_thresh,
+                            const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
+                            unsigned long long *mask, int *nan_flag);
 void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,
                       const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                       unsigned long long *mask);

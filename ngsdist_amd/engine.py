@@ -97,6 +97,15 @@ class Engine:
         _check(self._L.ngd_upload_sites(self._h, p.ctypes.data_as(C.POINTER(C.c_double)), int(s0), p.shape[0]))
         return self
 
+    def upload_raw_sites(self, raw, s0=0, in_logscale=False, call_geno=False, N_thresh=0.0, call_thresh=0.0):
+        """raw[n][n_ind][3]: doubles as stored in the binary GL file; prepared on the device."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        assert raw.ndim == 3 and raw.shape[1:] == (self.n_ind, 3), raw.shape
+        pr = _lib.NgdPrep(int(in_logscale), int(call_geno), float(N_thresh), float(call_thresh))
+        _check(self._L.ngd_upload_raw_sites(self._h, raw.ctypes.data_as(C.POINTER(C.c_double)), int(s0),
+                                            raw.shape[0], C.byref(pr)))
+        return self
+
     def commit(self):
         _check(self._L.ngd_commit(self._h))
         return self

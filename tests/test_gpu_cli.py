@@ -137,3 +137,22 @@ def test_text_gl_with_header_and_two_gpu_shards_on_one_device(tmp_path):
     exp = O.run_reference_flow(p, evol_model=1, indep_geno=True, n_threads=8)
     got = cli(tmp_path, "--geno", path, "--probs", "--n_ind", n_ind, "--n_sites", n_sites, "--indep_geno")
     assert got == exp
+
+
+def test_prep_on_device_prints_the_same_bytes(tmp_path):
+    base = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200]
+    for prep in ("host", "device"):
+        assert cli(tmp_path, *base, "--indep_geno", "--evol_model", 0, "--prep", prep) == golden("t_gl_I0.dist")
+        assert cli(tmp_path, *base, "--evol_model", 2, "--prep", prep) == golden("t_gl_EM2.dist")
+        assert cli(tmp_path, *base, "--call_geno", "--evol_model", 0, "--prep", prep) == golden("t_gl_CG.dist")
+
+
+def test_nan_in_binary_input_is_the_reference_error(tmp_path):
+    raw = np.fromfile(T_GL, dtype=np.float64).copy()
+    raw[100] = -1.0
+    bad = tmp_path / "bad.bin"
+    raw.tofile(str(bad))
+    for prep in ("host", "device"):
+        r = subprocess.run([BIN, "--geno", str(bad), "--probs", "--n_ind", "6", "--n_sites", "200", "--out",
+                            str(tmp_path / "o"), "--verbose", "0", "--prep", prep], capture_output=True)
+        assert r.returncode == 255 and b"NaN found! Is the file format correct?" in r.stderr

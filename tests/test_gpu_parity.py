@@ -241,3 +241,63 @@ def test_errors_are_codes_not_exits():
             e.run(np.array([0, 11], dtype=np.uint64), 1)  # map entry out of range
     with pytest.raises(n.NgdError):
         n.finish(np.zeros(1), np.ones(1, dtype=np.uint64), 0, 3)  # K80..TN93: reference error()s
+
+
+# ---- K0: kernel-input construction on the device (ngd_upload_raw_sites) ----------------------
+def _raw_gl(n_ind, n_sites, seed):
+    """unnormalised positive likelihood triples, site-major like the binary file, some exact zeros"""
+    rng = np.random.default_rng(seed)
+    raw = rng.gamma(0.4, size=(n_sites, n_ind, 3)) + 1e-12
+    raw[rng.random((n_sites, n_ind)) < 0.05] = [1.0, 0.0, 0.0]          # log(0) -> -inf -> -1e15 clamp
+    raw[rng.random((n_sites, n_ind)) < 0.05] = [0.25, 0.25, 0.25]       # missing
+    return raw
+
+
+@pytest.mark.parametrize("kernel,indep", [("mfma", True), ("stream", True), ("em_fast", False)])
+def test_device_prep_matches_host_prep(kernel, indep):
+    n_ind, n_sites = 50, 3001
+    raw = _raw_gl(n_ind, n_sites, 5)
+    p = O.prep_binary(raw, n_ind, n_sites)
+    so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, n_threads=8)
+    with N().Engine(n_ind, n_sites, pairwise_del=True, indep_geno=indep, kernel=kernel) as e:
+        e.upload_raw_sites(raw[:1000], 0).upload_raw_sites(raw[1000:], 1000).commit()
+        s, c = e.run()
+    assert np.array_equal(c, co)  # missing-site decisions identical
+    assert rel_err(s, so) < RTOL
+
+
+def test_device_prep_log_scale_and_call_geno():
+    n_ind, n_sites = 30, 2000
+    raw = _raw_gl(n_ind, n_sites, 6)
+    with np.errstate(divide="ignore"):
+        lraw = np.log(raw)
+    lraw[np.isinf(lraw)] = -1e15
+    for call in (None, (0.0, 0.0), (0.4, 0.95)):
+        kw = dict(call_geno=call is not None, N_thresh=call[0] if call else 0.0, call_thresh=call[1] if call else 0.0)
+        p = O.prep_binary(lraw, n_ind, n_sites, in_logscale=True, **kw)
+        so, co = O.all_pairs(p, n_threads=8)
+        with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+            s, c = e.upload_raw_sites(lraw, 0, in_logscale=True, **kw).commit().run()
+        assert np.array_equal(c, co)
+        assert rel_err(s, so) < RTOL
+    # every genotype called (no ties, thresholds 0): one-hot vectors -> dyadic terms -> bit-exact
+    rng = np.random.default_rng(8)
+    raw2 = rng.gamma(0.4, size=(n_sites, n_ind, 3)) + 1e-9
+    p = O.prep_binary(raw2, n_ind, n_sites, call_geno=True)
+    so, co = O.all_pairs(p, n_threads=8)
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+        s, c = e.upload_raw_sites(raw2, 0, call_geno=True).commit().run()
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+
+
+def test_device_prep_reports_nan_like_the_reference():
+    raw = _raw_gl(6, 100, 7)
+    raw[50, 3, 1] = -0.5  # log of a negative number
+    with N().Engine(6, 100) as e:
+        e.upload_raw_sites(raw, 0)
+        with pytest.raises(N().NgdError) as ei:
+            e.commit()
+        assert ei.value.code == -6 and "NaN found!" in str(ei.value)
+    with N().Engine(6, 100) as e:
+        with pytest.raises(N().NgdError):
+            e.upload_raw_sites(raw, 0, call_geno=True, N_thresh=0.9, call_thresh=0.5)
