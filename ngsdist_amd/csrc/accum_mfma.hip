@@ -11,8 +11,11 @@
 // per lane per operand for 1024 FMAs, so operand delivery (VGPR/LDS/L1 traffic)
 // drops 16x versus v_fma_f64 register tiles.
 //
-// Workgroup = 4 wavefronts = one 128x128 pair tile x one slice of k.
-// Wavefront  = 64x64 sub-tile = 4x4 MFMA tiles, 16 accumulators of 4 doubles.
+// Wavefront  = one JOB = a 64x64 block of pairs = 4x4 MFMA tiles, 16 accumulators of 4 doubles.
+// Workgroup  = 4 jobs x one slice of k.  The four jobs of an off-diagonal 128x128 tile share a
+// workgroup (their operands overlap); of a diagonal tile only the upper-right job is a full one, and
+// its two diagonal jobs run in a second launch whose MFMA pattern is the upper triangle only
+// (10 of 16 tiles).  Job lists are built by the engine (engine.hip).
 // Operands come straight from the fragment-major images (ngd_internal.h): one
 // coalesced 512-B global load per 16x4 operand, software-pipelined DEPTH k-groups
 // ahead in registers; the 4 wavefronts of a tile share operands through L1/L2.
@@ -34,23 +37,21 @@ constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
 // profiles/r01_fp64_peak_microbench.txt); the 64-cycle pipe rate needs two
 // wavefronts per SIMD that are BOTH in their MFMA phase, so a third resident
 // wavefront is what covers the others' load/wait/epilogue phases.
-template <bool WEIGHTED, int DEPTH, int WPS>
+template <bool WEIGHTED, int DEPTH, int WPS, bool TRI>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
-    const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad,
-    uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
+    const ngd_tile *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
+    uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
   const uint32_t xcd = b & 7u, q = b >> 3;
   const uint32_t tile = q % n_tiles;
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
-  const uint32_t ti = tiles[tile].ti, tj = tiles[tile].tj;
   // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wi = wave >> 1, wj = wave & 1;
-  if (ti == tj && wi > wj) return;  // strictly-lower sub-tile of a diagonal tile: never read
-  const uint32_t ig0 = ti * NGD_IG_PER_TILE + wi * WM;
-  const uint32_t jg0 = tj * NGD_IG_PER_TILE + wj * WN;
+  const ngd_tile job = jobs[tile * 4 + wave];  // first row group / first column group of the 64x64 block
+  if (job.ti == 0xFFFFu) return;                // padding entry of the job list
+  const uint32_t ig0 = job.ti, jg0 = job.tj;
 
   const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
           for (int m = 0; m < WM; m++)
 #pragma unroll
             for (int n = 0; n < WN; n++)
-              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
+              if (!TRI || m <= n)  // diagonal job: tiles below the diagonal hold no pair i1 < i2
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
         fetch(d, kg + d + DEPTH);
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     for (int n = 0; n < WN; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
+        if (TRI && m > n) continue;
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
         out[(uint64_t)i * n_pad + j] = acc[m][n][r];
@@ -162,25 +165,34 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 }  // namespace
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_tile *d_tiles, uint32_t n_tiles,
-                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
-  if (!n_tiles) return;
-  dim3 grid(n_tiles * n_ks), block(256);  // n_ks is a multiple of 8 (see the deal above)
+                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, const ngd_tile *d_jobs_tri,
+                           uint32_t n_wg_tri, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
+                           double *slab) {
+  // n_ks is a multiple of 8 (see the deal in the kernel)
   static const int variant = [] {
     const char *v = getenv("NGD_MFMA_VARIANT");
     return v && *v ? atoi(v) : 0;
   }();
-#define NGD_MFMA(W, D, P)                                                                          \
-  hipLaunchKernelGGL((k_accum_mfma<W, D, P>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, \
-                     g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
+#define NGD_MFMA(W, D, P, T, JOBS, NWG)                                                                  \
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P, T>), dim3((NWG) * n_ks), dim3(256), 0, st, PA, QB, d_ws, JOBS, \
+                     NWG, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
   // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
   // (profiles/r01_*): the third wavefront covers the others' load phases.
   // variant 1: 4-deep register ring, 2 wavefronts per SIMD.
   // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
-  if (d_ws) {
-    if (variant == 1) NGD_MFMA(true, 4, 2); else NGD_MFMA(true, 1, 3);
-  } else {
-    if (variant == 1) NGD_MFMA(false, 4, 2); else NGD_MFMA(false, 1, 3);
+  if (n_wg) {
+    if (d_ws) {
+      if (variant == 1) NGD_MFMA(true, 4, 2, false, d_jobs, n_wg); else NGD_MFMA(true, 1, 3, false, d_jobs, n_wg);
+    } else {
+      if (variant == 1) NGD_MFMA(false, 4, 2, false, d_jobs, n_wg); else NGD_MFMA(false, 1, 3, false, d_jobs, n_wg);
+    }
+  }
+  if (n_wg_tri) {
+    if (d_ws) {
+      if (variant == 1) NGD_MFMA(true, 4, 2, true, d_jobs_tri, n_wg_tri); else NGD_MFMA(true, 1, 3, true, d_jobs_tri, n_wg_tri);
+    } else {
+      if (variant == 1) NGD_MFMA(false, 4, 2, true, d_jobs_tri, n_wg_tri); else NGD_MFMA(false, 1, 3, true, d_jobs_tri, n_wg_tri);
+    }
   }
 #undef NGD_MFMA
 }

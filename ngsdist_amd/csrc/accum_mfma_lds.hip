@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge (64 x 64 pairs)
+constexpr int WN = 4;  // MFMA tile columns per wavefront (64 pairs); rows WM = 4 (4 waves) or 2 (8 waves)
 constexpr int KC = 2;          // k-groups per stage
 constexpr int NS = 3;          // stages in the LDS ring
 // stage = KC x (A: 8 fragments | B: 8 fragments) x 512 B = 16 KiB; ring = 48 KiB -> 3 workgroups per CU
@@ -30,8 +30,8 @@ constexpr int NS = 3;          // stages in the LDS ring
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-template <bool WEIGHTED>
-__global__ __launch_bounds__(256, 3) void k_accum_mfma_lds(
+template <bool WEIGHTED, int WM>
+__global__ __launch_bounds__(64 * (8 / WM) * 2, WM == 4 ? 3 : 4) void k_accum_mfma_lds(
     const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
     const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad,
     uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256, 3) void k_accum_mfma_lds(
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
   const uint32_t ti = tiles[tile].ti, tj = tiles[tile].tj;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  constexpr int NW = (8 / WM) * 2;  // wavefronts per workgroup: (8/WM) rows x 2 columns of sub-tiles
   const int wi = wave >> 1, wj = wave & 1;
-  const bool idle = (ti == tj && wi > wj);  // strictly-lower sub-tile: loads its share, computes nothing
+  // sub-tile rows [wi*WM*16, +WM*16) x columns [wj*64, +64): strictly below the diagonal of a diagonal
+  // tile when its first row is past its last column -> loads its share, computes nothing
+  const bool idle = (ti == tj && wi * WM >= (wj + 1) * WN);
 
   const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
@@ -57,28 +60,34 @@ __global__ __launch_bounds__(256, 3) void k_accum_mfma_lds(
 #pragma unroll
     for (int n = 0; n < WN; n++) acc[m][n] = (ngd_d4){0, 0, 0, 0};
 
-  // DMA duty of this wavefront: k-group (wave>>1) of the stage, panel (wave&1): 0 = A rows, 1 = B rows;
-  // 4 pieces of 1 KiB = fragment pairs 0..3 of that panel (8 fragments = 4 KiB contiguous in the image).
-  const int d_kgl = wave >> 1, d_half = wave & 1;
+  // DMA duty of this wavefront.  A stage is 16 pieces of 1 KiB: (k-group, panel A|B, fragment pair 0..3);
+  // with 4 waves each takes one (k-group, panel) = 4 pieces, with 8 waves half of one = 2 pieces.
+  constexpr int PIECES = 16 / NW;
+  const int d_unit = wave * PIECES / 4;                 // (k-group, panel) index 0..3
+  const int d_kgl = d_unit >> 1, d_half = d_unit & 1;
+  const int d_q0 = (wave * PIECES) % 4;                 // first fragment pair
   const uint64_t kstride = (uint64_t)n_ig * 64;
   const double *src0 = (d_half ? QB + (uint64_t)tj * NGD_IG_PER_TILE * 64 : PA + (uint64_t)ti * NGD_IG_PER_TILE * 64) +
-                       (kg0 + d_kgl) * kstride + lane * 2;
+                       (kg0 + d_kgl) * kstride + d_q0 * 128 + lane * 2;
 
   auto dma = [&](uint32_t stage) {  // stage index may run past the slice: tail padding keeps it in bounds
     const double *src = src0 + (uint64_t)stage * KC * kstride;
-    double *dst = &ring[stage % NS][d_kgl][d_half][0][0];
+    double *dst = &ring[stage % NS][d_kgl][d_half][d_q0 * 2][0];
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 3072, 0);
+    if (PIECES == 4) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 3072, 0);
+    }
   };
 
   if (n_stage) {
     dma(0);
     dma(1);
     for (uint32_t t = 0; t < n_stage; t++) {
-      // my pieces of stage t have landed when at most the 4 pieces of stage t+1 are still in flight
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // my pieces of stage t have landed when at most the PIECES pieces of stage t+1 are still in flight
+      if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everyone's pieces of stage t are in; everyone is done reading stage t-1
       dma(t + 2);                    // refill the slot stage t-1 occupied
       if (!idle) {
@@ -133,11 +142,18 @@ void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *
                                const uint32_t *d_ws, const ngd_tile *d_tiles, uint32_t n_tiles,
                                uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
   if (!n_tiles) return;
-  dim3 grid(n_tiles * n_ks), block(256);
-  if (d_ws)
-    hipLaunchKernelGGL((k_accum_mfma_lds<true>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, g.n_ig,
-                       g.n_pad, kg_per_slice, n_kg_eff, slab);
-  else
-    hipLaunchKernelGGL((k_accum_mfma_lds<false>), grid, block, 0, st, PA, QB, d_ws, d_tiles, n_tiles, g.n_ig,
-                       g.n_pad, kg_per_slice, n_kg_eff, slab);
+  dim3 grid(n_tiles * n_ks);
+  static const int variant = [] {
+    const char *v = getenv("NGD_MFMA_VARIANT");
+    return v && *v ? atoi(v) : 0;
+  }();
+#define NGD_LDS(W, M)                                                                                      \
+  hipLaunchKernelGGL((k_accum_mfma_lds<W, M>), grid, dim3(64 * (8 / M) * 2), 0, st, PA, QB, d_ws, d_tiles, \
+                     n_tiles, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
+  if (variant == 3) {  // 8 wavefronts of 32 x 64 pairs, 4 per SIMD
+    if (d_ws) NGD_LDS(true, 2); else NGD_LDS(false, 2);
+  } else {             // 4 wavefronts of 64 x 64 pairs, 3 per SIMD
+    if (d_ws) NGD_LDS(true, 4); else NGD_LDS(false, 4);
+  }
+#undef NGD_LDS
 }

@@ -46,6 +46,9 @@ struct ngd_engine {
   // shard
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
   uint32_t n_tiles = 0, n_tiles16 = 0;
+  // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
+  ngd_tile *d_jobs = nullptr, *d_jobs_tri = nullptr;
+  uint32_t n_wg = 0, n_wg_tri = 0;
   uint64_t *d_pairs = nullptr;
   uint64_t n_owned_pairs = 0;
   // scratch + results
@@ -106,7 +109,7 @@ void ngd_destroy(ngd_engine *e) {
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_block_map, e->d_mult, e->d_ws,
-                  e->d_tiles, e->d_tiles16, e->d_pairs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
+                  e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->d_jobs_tri, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -200,6 +203,31 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     }
   e->n_tiles = (uint32_t)tiles.size();
   e->n_tiles16 = (uint32_t)tiles16.size();
+  // job lists of the MFMA kernel (units: 16-individual groups)
+  std::vector<ngd_tile> jobs, jobs_tri, loose;
+  for (const ngd_tile &t : tiles) {
+    const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
+    if (t.ti != t.tj) {
+      for (uint16_t a = 0; a < 2; a++)
+        for (uint16_t b = 0; b < 2; b++) jobs.push_back({(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b)});
+    } else {
+      loose.push_back({r0, (uint16_t)(c0 + 4)});  // the full block above the diagonal
+      jobs_tri.push_back({r0, c0});
+      jobs_tri.push_back({(uint16_t)(r0 + 4), (uint16_t)(c0 + 4)});
+    }
+  }
+  for (const ngd_tile &j : loose) jobs.push_back(j);  // grouped four to a workgroup
+  auto drop_padding = [&](std::vector<ngd_tile> &v) {  // blocks made only of padding individuals
+    std::vector<ngd_tile> keep;
+    for (const ngd_tile &j : v)
+      if ((uint64_t)j.ti * 16 < g.n_ind && (uint64_t)j.tj * 16 < g.n_ind) keep.push_back(j);
+    while (keep.size() % 4) keep.push_back({0xFFFF, 0xFFFF});
+    v.swap(keep);
+  };
+  drop_padding(jobs);
+  drop_padding(jobs_tri);
+  e->n_wg = (uint32_t)(jobs.size() / 4);
+  e->n_wg_tri = (uint32_t)(jobs_tri.size() / 4);
   if (kernel == NGD_KERNEL_STREAM && world > 1) {
     for (const ngd_tile &t : tiles)
       for (uint64_t i = (uint64_t)t.ti * NGD_TILE; i < std::min<uint64_t>(g.n_ind, (t.ti + 1ull) * NGD_TILE); i++)
@@ -229,6 +257,14 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   TRY(dev_alloc(e, &e->d_tiles, tiles.size(), false));
   TRY(dev_alloc(e, &e->d_tiles16, tiles16.size(), false));
   TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
+  TRY(dev_alloc(e, &e->d_jobs, jobs.size(), false));
+  TRY(dev_alloc(e, &e->d_jobs_tri, jobs_tri.size(), false));
+  if (!jobs.empty())
+    if (hipMemcpy(e->d_jobs, jobs.data(), jobs.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: job list upload failed"));
+  if (!jobs_tri.empty())
+    if (hipMemcpy(e->d_jobs_tri, jobs_tri.data(), jobs_tri.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: job list upload failed"));
   if (!tiles.empty())
     if (hipMemcpy(e->d_tiles, tiles.data(), tiles.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
@@ -257,7 +293,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // ---- split over the site axis: slices -> slabs, reduced in fixed order ----
   if (kernel == NGD_KERNEL_MFMA) {
     uint64_t want = env_u64("NGD_MFMA_WG", 8192);
-    uint64_t ks = e->n_tiles ? (want + e->n_tiles - 1) / e->n_tiles : 8;
+    const uint32_t wg_per_slice = std::max(1u, e->n_wg + e->n_wg_tri);
+    uint64_t ks = (want + wg_per_slice - 1) / wg_per_slice;
     uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 64));
     ks = std::min(ks, max_ks);
     ks = env_u64("NGD_MFMA_KS", ks);
@@ -458,10 +495,11 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
                         double *slab) {
     switch (e->kernel) {
       case NGD_KERNEL_MFMA:
-        if (env_u64("NGD_MFMA_VARIANT", 0) == 2)
+        if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
           ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
         else
-          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, e->d_jobs_tri, e->n_wg_tri, n_ks,
+                                per_slice, kg_lim, slab);
         break;
       default:
         ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -480,7 +518,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
     if (!mfma || block_size % 4 == 0) {
       // split large blocks so that there are enough workgroups; slices of one block share its weight
       const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
-      const uint32_t tiles_n = mfma ? e->n_tiles : e->n_tiles16;
+      const uint32_t tiles_n = mfma ? e->n_wg + e->n_wg_tri : e->n_tiles16;
       uint64_t sub = 1;
       const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
       while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)

@@ -40,6 +40,44 @@ __global__ __launch_bounds__(256, WPS) void k_mfma(double *out, stamp *st, int i
   if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = {c1 - c0, r1 - r0};
 }
 
+// 4x4 tile fed from LDS with RANDOM operands that change every step (what a real kernel does):
+// constant operands under-state the power an MFMA draws and over-state the clock it can hold.
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void k_mfma_lds_random(double *out, stamp *st, int iters, double a0, double b0) {
+  __shared__ double tab[8][16][64];  // 8 steps x (4 A + 4 B + spare) fragments of 64 lanes
+  unsigned long long z = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1) + blockIdx.x;
+  for (int k = threadIdx.x; k < 8 * 16 * 64; k += 256) {
+    z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+    (&tab[0][0][0])[k] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0, 0, 0, 0};
+  unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+    const int stp = (it + wave) & 7;
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = tab[stp][i][lane]; b[i] = tab[stp][4 + i][lane]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = {c1 - c0, r1 - r0};
+}
+
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void k_mfma_agpr(double *out, stamp *st, int iters, double a0, double b0) {
   d4 acc[4][4];
@@ -155,6 +193,8 @@ int main() {
   hipMalloc(&dst, 2048 * 4 * sizeof(stamp));
   hipEventCreate(&e0); hipEventCreate(&e1);
   printf("--- operand scale 1 (values grow), then scale 1e-3 (values stay in [0,1]) ---\n");
+  run("mfma 4x4 LDS random 2w/SIMD", [](int g, int it) { hipLaunchKernelGGL((k_mfma_lds_random<2>), dim3(g), dim3(256), 0, 0, out, dst, it, 0, 0); }, 512, 16, 40000, 2048);
+  run("mfma 4x4 LDS random 3w/SIMD", [](int g, int it) { hipLaunchKernelGGL((k_mfma_lds_random<3>), dim3(g), dim3(256), 0, 0, out, dst, it, 0, 0); }, 768, 16, 40000, 2048);
   run("mfma 4x4 AGPR 1w/SIMD", [](int g, int it) { hipLaunchKernelGGL((k_mfma_agpr<1>), dim3(g), dim3(256), 0, 0, out, dst, it, 1e-3, 2e-3); }, 256, 16, 20000, 2048);
   run("mfma 4x4 AGPR 2w/SIMD", [](int g, int it) { hipLaunchKernelGGL((k_mfma_agpr<2>), dim3(g), dim3(256), 0, 0, out, dst, it, 1e-3, 2e-3); }, 512, 16, 20000, 2048);
   for (double sc : {1e-3}) {
