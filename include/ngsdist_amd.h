@@ -61,8 +61,8 @@ typedef struct ngd_config {
   int32_t indep_geno;   /* params.indep_geno, ngsDist.cpp:348-353             */
   int32_t device;       /* HIP device ordinal; -1 = current device            */
   int32_t kernel;       /* NGD_KERNEL_*                                       */
-  uint32_t shard_rank;  /* this engine computes pair tiles t with             */
-  uint32_t shard_world; /*   t % shard_world == shard_rank; 0/1 = everything  */
+  uint32_t shard_rank;  /* this engine computes the pair tiles that            */
+  uint32_t shard_world; /*   ngd_shard_of_pair() gives it; 0/1 = everything   */
   uint32_t reserved[6]; /* must be zero                                       */
 } ngd_config;
 
@@ -176,7 +176,8 @@ void ngd_boot_block_map(uint32_t state[3], uint64_t n_blocks, uint64_t *block_ma
 uint64_t ngd_n_pairs(uint64_t n_ind);
 uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
 /* the shard (0 .. shard_world-1) that computes pair i1 < i2: 128 x 128 pair tiles of
- * the upper triangle, row-major, dealt round-robin.  Pure host arithmetic. */
+ * the upper triangle, dealt by cost (off-diagonal tiles first) to the least loaded
+ * shard -- the rule ngd_create() uses.  Pure host arithmetic. */
 uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world);
 /* bytes of device memory the engine holds for this configuration */
 uint64_t ngd_device_bytes(const ngd_engine *e);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ngd_internal.h"
+#include "ngd_shard.h"
 
 static thread_local std::string g_err;
 
@@ -185,13 +186,14 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   for (auto &v : e->ev)
     if (hipEventCreate(&v) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
 
-  // ---- shard: upper-triangular 128-tiles dealt round-robin over ranks ----
+  // ---- shard: upper-triangular 128-tiles dealt by cost over ranks (ngd_shard.h) ----
   std::vector<ngd_tile> tiles, tiles16;
   std::vector<uint64_t> pairs;
+  const std::vector<uint32_t> owner = ngd_tile_owners(g.n_t, world);
   uint32_t tid = 0;
   for (uint32_t ti = 0; ti < g.n_t; ti++)
     for (uint32_t tj = ti; tj < g.n_t; tj++, tid++) {
-      if (tid % world != cfg->shard_rank) continue;
+      if (owner[tid] != cfg->shard_rank) continue;
       tiles.push_back({(uint16_t)ti, (uint16_t)tj});
       for (uint32_t a = 0; a < NGD_IG_PER_TILE; a++)
         for (uint32_t b = 0; b < NGD_IG_PER_TILE; b++) {

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/ngsdist_amd.h"
+#include "ngd_shard.h"
 
 namespace {
 // gsl_rng_taus: GSL is a third-party dependency of the reference (README.md:20,
@@ -65,13 +66,18 @@ void ngd_boot_block_map(uint32_t st[3], uint64_t n_blocks, uint64_t *block_map) 
   }
 }
 
-// Which shard computes pair (i1 < i2): pair tiles of 128 x 128 individuals, upper
-// triangle enumerated row-major, dealt round-robin (the same rule ngd_create uses).
+// Which shard computes pair (i1 < i2): the owner of its 128 x 128 pair tile (ngd_shard.h).
 uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world) {
   if (shard_world <= 1) return 0;
-  const uint64_t n_t = (n_ind + 127) / 128, ti = i1 / 128, tj = i2 / 128;
-  const uint64_t tid = ti * n_t - ti * (ti - 1) / 2 - ti + tj;  // sum_{r<ti}(n_t - r) + (tj - ti)
-  return (uint32_t)(tid % shard_world);
+  static thread_local uint32_t c_nt = 0, c_world = 0;
+  static thread_local std::vector<uint32_t> c_owner;
+  const uint32_t n_t = (uint32_t)((n_ind + 127) / 128);
+  if (c_nt != n_t || c_world != shard_world) {
+    c_owner = ngd_tile_owners(n_t, shard_world);
+    c_nt = n_t;
+    c_world = shard_world;
+  }
+  return c_owner[ngd_tile_id(n_t, i1 / 128, i2 / 128)];
 }
 
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites,

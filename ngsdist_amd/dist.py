@@ -24,9 +24,12 @@ def shard_of_pairs(n_ind, world):
 
 def merge_shards(sum_t, cnt_t, dst=0):
     """In-place: after the call rank `dst` holds every pair.  sum_t float64,
-    cnt_t int64 torch tensors (device tensors under RCCL, CPU tensors under gloo)."""
+    cnt_t int64 torch tensors (device tensors under RCCL, CPU tensors under gloo).
+    cnt_t may be None when the count is the same for every pair (no --pairwise_del):
+    the caller then fills it in without a collective."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     dist.reduce(sum_t, dst=dst, op=dist.ReduceOp.SUM)
-    dist.reduce(cnt_t, dst=dst, op=dist.ReduceOp.SUM)
+    if cnt_t is not None:
+        dist.reduce(cnt_t, dst=dst, op=dist.ReduceOp.SUM)

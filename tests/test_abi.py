@@ -112,5 +112,18 @@ def test_shard_of_pair_partitions(lib):
     for world in (1, 2, 3, 8):
         owners = {lib.ngd_shard_of_pair(n, i, j, world) for i in (0, 127, 128, 299) for j in range(i + 1, n, 37)}
         assert owners <= set(range(world))
-    assert lib.ngd_shard_of_pair(n, 0, 1, 4) == 0 and lib.ngd_shard_of_pair(n, 0, 128, 4) == 1
-    assert lib.ngd_shard_of_pair(n, 128, 129, 4) == 3 and lib.ngd_shard_of_pair(n, 256, 257, 4) == 5 % 4
+    # one owner per 128 x 128 tile
+    assert lib.ngd_shard_of_pair(n, 0, 1, 4) == lib.ngd_shard_of_pair(n, 5, 127, 4)
+    assert lib.ngd_shard_of_pair(n, 0, 128, 4) == lib.ngd_shard_of_pair(n, 127, 255, 4)
+
+
+def test_shard_loads_are_balanced(lib):
+    # cfg 3 geometry: 8 tile rows, 28 off-diagonal tiles (cost 64) + 8 diagonal (cost 36)
+    n = 1000
+    for world in (2, 4, 8):
+        load = [0] * world
+        for ti in range(8):
+            for tj in range(ti, 8):
+                r = lib.ngd_shard_of_pair(n, ti * 128, min(n - 1, tj * 128 + 1 if tj > ti else ti * 128 + 1), world)
+                load[r] += 36 if ti == tj else 64
+        assert max(load) / (sum(load) / world) < 1.03
