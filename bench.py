@@ -222,6 +222,18 @@ def main():
                 "pair_sites_per_s": pair_sites_per_launch_all / world / t_acc,
                 "algorithmic": "FP64 VALU bound; flops are data dependent (EM iterations per site)"}
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+    # figure is the one the last tools/profile.sh run of this same command left in profiles/
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, kernel))))
+        for kname, v in tj["per_launch"].items():
+            if "accum" in kname and "TRI" not in kname:
+                roof["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
+                roof["traffic_source"] = "profiles/traffic_%s_%s.json (%s)" % (args.workload, kernel, tj["source"])
+                break
+    except Exception:
+        pass
+
     out = {
         "metric": "pair-distances/sec", "value": value, "unit": "pair-distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

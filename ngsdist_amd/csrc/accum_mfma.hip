@@ -13,9 +13,11 @@
 //
 // Wavefront  = one JOB = a 64x64 block of pairs = 4x4 MFMA tiles, 16 accumulators of 4 doubles.
 // Workgroup  = 4 jobs x one slice of k.  The four jobs of an off-diagonal 128x128 tile share a
-// workgroup (their operands overlap); of a diagonal tile only the upper-right job is a full one, and
-// its two diagonal jobs run in a second launch whose MFMA pattern is the upper triangle only
-// (10 of 16 tiles).  Job lists are built by the engine (engine.hip).
+// workgroup (their operands overlap); a diagonal tile gives one full job and two jobs ON the
+// diagonal, whose MFMA pattern is the upper triangle only (10 of 16 tiles) -- same launch, same
+// slice, so their rows are read while the off-diagonal jobs of that slice have them in L2 (as a
+// separate launch the diagonal jobs re-streamed the whole data set: 49 GB for 8 % of the flops).
+// Job lists are built by the engine (engine.hip).
 // Operands come straight from the fragment-major images (ngd_internal.h): one
 // coalesced 512-B global load per 16x4 operand, software-pipelined DEPTH k-groups
 // ahead in registers; the 4 wavefronts of a tile share operands through L1/L2.
@@ -37,7 +39,8 @@ constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
 // profiles/r01_fp64_peak_microbench.txt); the 64-cycle pipe rate needs two
 // wavefronts per SIMD that are BOTH in their MFMA phase, so a third resident
 // wavefront is what covers the others' load/wait/epilogue phases.
-template <bool WEIGHTED, int DEPTH, int WPS, bool TRI>
+// TRI_JOBS: build the triangular pattern for blocks on the diagonal (else they run the full one)
+template <bool WEIGHTED, int DEPTH, int WPS, bool TRI_JOBS>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
     const ngd_tile *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
@@ -49,9 +52,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
   // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const ngd_tile job = jobs[tile * 4 + wave];  // first row group / first column group of the 64x64 block
-  if (job.ti == 0xFFFFu) return;                // padding entry of the job list
-  const uint32_t ig0 = job.ti, jg0 = job.tj;
+  const ngd_tile job = jobs[tile * 4 + wave];  // first row / column group of the 64x64 block
+  if (job.ti == 0xFFFFu) return;               // padding entry of the job list
+  // blocks ON the diagonal carry a flag: their MFMA tiles below the diagonal hold no pair i1 < i2
+  const bool tri = __builtin_amdgcn_readfirstlane(job.tj >> 15) != 0;
+  const uint32_t ig0 = job.ti, jg0 = job.tj & 0x7FFFu;
 
   const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
@@ -117,10 +122,14 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   static_assert(WM == 4 && WN == 4, "the asm fetch is written for 4+4 operands");
   static_assert(DEPTH >= 1 && DEPTH <= NGD_KG_TAIL, "tail padding must cover the run-ahead");
 
-  if (kg0 < kg1) {
+  // Prologue, k loop and drain as ONE unit per MFMA pattern (full: 16 tiles, triangular: 10).  The
+  // two instantiations must not share a control-flow join while loads are in flight: the asm loads
+  // are invisible to the compiler, so a register copy it placed at such a join would read a
+  // register the load has not written yet.
+  auto run = [&](auto tri_c) {
+    constexpr bool TRI = decltype(tri_c)::value;
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, kg0 + d);
-
     for (uint64_t kg = kg0; kg < kg1; kg += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
           for (int m = 0; m < WM; m++)
 #pragma unroll
             for (int n = 0; n < WN; n++)
-              if (!TRI || m <= n)  // diagonal job: tiles below the diagonal hold no pair i1 < i2
+              if (!TRI || m <= n)
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
@@ -145,6 +154,10 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
     __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (kg0 < kg1) {
+    if (TRI_JOBS && tri) run(std::true_type{}); else run(std::false_type{});
   }
 
   // D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*r
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     for (int n = 0; n < WN; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (TRI && m > n) continue;
+        if (TRI_JOBS && tri && m > n) continue;
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
         out[(uint64_t)i * n_pad + j] = acc[m][n][r];
@@ -165,34 +178,35 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 }  // namespace
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, const ngd_tile *d_jobs_tri,
-                           uint32_t n_wg_tri, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
-                           double *slab) {
+                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, uint32_t n_ks,
+                           uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
+  if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)
   static const int variant = [] {
     const char *v = getenv("NGD_MFMA_VARIANT");
     return v && *v ? atoi(v) : 0;
   }();
-#define NGD_MFMA(W, D, P, T, JOBS, NWG)                                                                  \
-  hipLaunchKernelGGL((k_accum_mfma<W, D, P, T>), dim3((NWG) * n_ks), dim3(256), 0, st, PA, QB, d_ws, JOBS, \
-                     NWG, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
+  static const int tri_jobs = [] {
+    const char *v = getenv("NGD_MFMA_TRI");
+    return v && *v ? atoi(v) : 0;
+  }();
+#define NGD_MFMA(W, D, P)                                                                                    \
+  do {                                                                                                       \
+    if (tri_jobs)                                                                                            \
+      hipLaunchKernelGGL((k_accum_mfma<W, D, P, true>), dim3(n_wg * n_ks), dim3(256), 0, st, PA, QB, d_ws,    \
+                         d_jobs, n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);                       \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_accum_mfma<W, D, P, false>), dim3(n_wg * n_ks), dim3(256), 0, st, PA, QB, d_ws,   \
+                         d_jobs, n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);                       \
+  } while (0)
   // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
   // (profiles/r01_*): the third wavefront covers the others' load phases.
   // variant 1: 4-deep register ring, 2 wavefronts per SIMD.
   // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
-  if (n_wg) {
-    if (d_ws) {
-      if (variant == 1) NGD_MFMA(true, 4, 2, false, d_jobs, n_wg); else NGD_MFMA(true, 1, 3, false, d_jobs, n_wg);
-    } else {
-      if (variant == 1) NGD_MFMA(false, 4, 2, false, d_jobs, n_wg); else NGD_MFMA(false, 1, 3, false, d_jobs, n_wg);
-    }
-  }
-  if (n_wg_tri) {
-    if (d_ws) {
-      if (variant == 1) NGD_MFMA(true, 4, 2, true, d_jobs_tri, n_wg_tri); else NGD_MFMA(true, 1, 3, true, d_jobs_tri, n_wg_tri);
-    } else {
-      if (variant == 1) NGD_MFMA(false, 4, 2, true, d_jobs_tri, n_wg_tri); else NGD_MFMA(false, 1, 3, true, d_jobs_tri, n_wg_tri);
-    }
+  if (d_ws) {
+    if (variant == 1) NGD_MFMA(true, 4, 2); else NGD_MFMA(true, 1, 3);
+  } else {
+    if (variant == 1) NGD_MFMA(false, 4, 2); else NGD_MFMA(false, 1, 3);
   }
 #undef NGD_MFMA
 }

@@ -35,7 +35,8 @@ struct ngd_engine {
   ngd_score sc{};
   int device = 0;
   int kernel = 0;  // resolved NGD_KERNEL_*
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;  // st2: the diagonal-block launch of the MFMA kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[5] = {};
   // resident data set
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
@@ -122,6 +123,9 @@ void ngd_destroy(ngd_engine *e) {
   if (e->d_nan) hipFree(e->d_nan);
   for (auto &v : e->ev)
     if (v) hipEventDestroy(v);
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->st2) hipStreamDestroy(e->st2);
   if (e->st) hipStreamDestroy(e->st);
   delete e;
 }
@@ -183,8 +187,13 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   };
   if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(NGD_E_HIP, "ngd_create: hipStreamCreate failed"));
+  if (hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(NGD_E_HIP, "ngd_create: hipStreamCreate failed"));
   for (auto &v : e->ev)
     if (hipEventCreate(&v) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
+  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
 
   // ---- shard: upper-triangular 128-tiles dealt by cost over ranks (ngd_shard.h) ----
   std::vector<ngd_tile> tiles, tiles16;
@@ -205,31 +214,29 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     }
   e->n_tiles = (uint32_t)tiles.size();
   e->n_tiles16 = (uint32_t)tiles16.size();
-  // job lists of the MFMA kernel (units: 16-individual groups)
-  std::vector<ngd_tile> jobs, jobs_tri, loose;
+  // job list of the MFMA kernel (units: 16-individual groups; bit 15 of tj = block on the diagonal).
+  // Off-diagonal tile -> its four 64x64 blocks in one workgroup; diagonal tile -> its upper-right
+  // block and its two diagonal blocks (+ one empty slot) in one workgroup.
+  std::vector<ngd_tile> jobs;
+  auto live = [&](uint16_t r, uint16_t c) { return (uint64_t)r * 16 < g.n_ind && (uint64_t)c * 16 < g.n_ind; };
   for (const ngd_tile &t : tiles) {
     const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
+    ngd_tile wg[4];
     if (t.ti != t.tj) {
       for (uint16_t a = 0; a < 2; a++)
-        for (uint16_t b = 0; b < 2; b++) jobs.push_back({(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b)});
+        for (uint16_t b = 0; b < 2; b++) wg[2 * a + b] = {(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b)};
     } else {
-      loose.push_back({r0, (uint16_t)(c0 + 4)});  // the full block above the diagonal
-      jobs_tri.push_back({r0, c0});
-      jobs_tri.push_back({(uint16_t)(r0 + 4), (uint16_t)(c0 + 4)});
+      wg[0] = {r0, (uint16_t)(c0 | 0x8000)};
+      wg[1] = {r0, (uint16_t)(c0 + 4)};
+      wg[2] = {(uint16_t)(r0 + 4), (uint16_t)((c0 + 4) | 0x8000)};
+      wg[3] = {0xFFFF, 0xFFFF};
+    }
+    for (ngd_tile &j : wg) {
+      if (j.ti != 0xFFFF && !live(j.ti, j.tj & 0x7FFF)) j = {0xFFFF, 0xFFFF};  // only padding individuals
+      jobs.push_back(j);
     }
   }
-  for (const ngd_tile &j : loose) jobs.push_back(j);  // grouped four to a workgroup
-  auto drop_padding = [&](std::vector<ngd_tile> &v) {  // blocks made only of padding individuals
-    std::vector<ngd_tile> keep;
-    for (const ngd_tile &j : v)
-      if ((uint64_t)j.ti * 16 < g.n_ind && (uint64_t)j.tj * 16 < g.n_ind) keep.push_back(j);
-    while (keep.size() % 4) keep.push_back({0xFFFF, 0xFFFF});
-    v.swap(keep);
-  };
-  drop_padding(jobs);
-  drop_padding(jobs_tri);
   e->n_wg = (uint32_t)(jobs.size() / 4);
-  e->n_wg_tri = (uint32_t)(jobs_tri.size() / 4);
   if (kernel == NGD_KERNEL_STREAM && world > 1) {
     for (const ngd_tile &t : tiles)
       for (uint64_t i = (uint64_t)t.ti * NGD_TILE; i < std::min<uint64_t>(g.n_ind, (t.ti + 1ull) * NGD_TILE); i++)
@@ -260,13 +267,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   TRY(dev_alloc(e, &e->d_tiles16, tiles16.size(), false));
   TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
   TRY(dev_alloc(e, &e->d_jobs, jobs.size(), false));
-  TRY(dev_alloc(e, &e->d_jobs_tri, jobs_tri.size(), false));
   if (!jobs.empty())
     if (hipMemcpy(e->d_jobs, jobs.data(), jobs.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(NGD_E_HIP, "ngd_create: job list upload failed"));
-  if (!jobs_tri.empty())
-    if (hipMemcpy(e->d_jobs_tri, jobs_tri.data(), jobs_tri.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
-      return bail(fail(NGD_E_HIP, "ngd_create: job list upload failed"));
+
   if (!tiles.empty())
     if (hipMemcpy(e->d_tiles, tiles.data(), tiles.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
@@ -295,7 +299,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // ---- split over the site axis: slices -> slabs, reduced in fixed order ----
   if (kernel == NGD_KERNEL_MFMA) {
     uint64_t want = env_u64("NGD_MFMA_WG", 8192);
-    const uint32_t wg_per_slice = std::max(1u, e->n_wg + e->n_wg_tri);
+    const uint32_t wg_per_slice = std::max(1u, e->n_wg);
     uint64_t ks = (want + wg_per_slice - 1) / wg_per_slice;
     uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 64));
     ks = std::min(ks, max_ks);
@@ -500,8 +504,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
         if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
           ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
         else
-          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, e->d_jobs_tri, e->n_wg_tri, n_ks,
-                                per_slice, kg_lim, slab);
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, n_ks, per_slice, kg_lim, slab);
         break;
       default:
         ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -520,7 +523,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
     if (!mfma || block_size % 4 == 0) {
       // split large blocks so that there are enough workgroups; slices of one block share its weight
       const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
-      const uint32_t tiles_n = mfma ? e->n_wg + e->n_wg_tri : e->n_tiles16;
+      const uint32_t tiles_n = mfma ? e->n_wg : e->n_tiles16;
       uint64_t sub = 1;
       const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
       while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)

@@ -81,9 +81,8 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
 
 // accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, const ngd_tile *d_jobs_tri,
-                           uint32_t n_wg_tri, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
-                           double *slab);
+                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, uint32_t n_ks,
+                           uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
 
 // accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
 void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,

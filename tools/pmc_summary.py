@@ -59,6 +59,7 @@ for p in ("fetch", "write", "sq", "l2", "l1"):
             agg[(k, c)] = mean
             print("| %s | %s | %s | %d | %.6g |" % (p, k, c, len(ids), mean))
 print()
+traffic = {}
 print("## derived (dominant accumulation kernel)\n")
 for k in sorted({k for (k, _) in agg}):
     if "accum" not in k:
@@ -70,8 +71,10 @@ for k in sorted({k for (k, _) in agg}):
         # bytes of a wide coalesced streaming read -> double it; WRITE_SIZE is exact.
         fb = g("FETCH_SIZE") * 1024 * 2
         print("- HBM read bytes per launch  = FETCH_SIZE x 1024 x 2 (gfx950 correction) = %.4g GB" % (fb / 1e9))
+        traffic.setdefault(k, {})["read_bytes"] = fb
     if g("WRITE_SIZE") is not None:
         print("- HBM write bytes per launch = WRITE_SIZE x 1024 = %.4g GB" % (g("WRITE_SIZE") * 1024 / 1e9))
+        traffic.setdefault(k, {})["write_bytes"] = g("WRITE_SIZE") * 1024
     if g("TCC_HIT") is not None and g("TCC_MISS") is not None:
         print("- L2 hit rate = %.3f" % (g("TCC_HIT") / (g("TCC_HIT") + g("TCC_MISS"))))
     if g("TCP_TOTAL_CACHE_ACCESSES") and g("TCP_TCC_READ_REQ") is not None:
@@ -89,3 +92,9 @@ for k in sorted({k for (k, _) in agg}):
             print("- effective shader clock = GRBM_GUI_ACTIVE / 8 / kernel time = %.0f MHz (kernel %.3f ms)" % (
                 g("GRBM_GUI_ACTIVE") / 8 / (kt_ms[k] * 1e-3) / 1e6, kt_ms[k]))
     print()
+
+if traffic:
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
+        json.dump({"source": os.path.basename(out), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+                   "FETCH_SIZE x 1024 x 2 (gfx950: reads of a wide coalesced stream are counted at half), WRITE_SIZE x 1024",
+                   "per_launch": traffic}, fh, indent=1)
