@@ -217,25 +217,32 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // job list of the MFMA kernel (units: 16-individual groups; bit 15 of tj = block on the diagonal).
   // Off-diagonal tile -> its four 64x64 blocks in one workgroup; diagonal tile -> its upper-right
   // block and its two diagonal blocks (+ one empty slot) in one workgroup.
-  std::vector<ngd_tile> jobs;
+  std::vector<ngd_tile> jobs, diag;
   auto live = [&](uint16_t r, uint16_t c) { return (uint64_t)r * 16 < g.n_ind && (uint64_t)c * 16 < g.n_ind; };
+  const bool pack_diag = env_u64("NGD_MFMA_PACK_DIAG", 1) != 0;
   for (const ngd_tile &t : tiles) {
     const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
     ngd_tile wg[4];
     if (t.ti != t.tj) {
       for (uint16_t a = 0; a < 2; a++)
         for (uint16_t b = 0; b < 2; b++) wg[2 * a + b] = {(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b)};
+      for (ngd_tile &j : wg) {
+        if (!live(j.ti, j.tj)) j = {0xFFFF, 0xFFFF};  // only padding individuals
+        jobs.push_back(j);
+      }
     } else {
       wg[0] = {r0, (uint16_t)(c0 | 0x8000)};
       wg[1] = {r0, (uint16_t)(c0 + 4)};
       wg[2] = {(uint16_t)(r0 + 4), (uint16_t)((c0 + 4) | 0x8000)};
-      wg[3] = {0xFFFF, 0xFFFF};
-    }
-    for (ngd_tile &j : wg) {
-      if (j.ti != 0xFFFF && !live(j.ti, j.tj & 0x7FFF)) j = {0xFFFF, 0xFFFF};  // only padding individuals
-      jobs.push_back(j);
+      for (int k = 0; k < 3; k++)
+        if (live(wg[k].ti, wg[k].tj & 0x7FFF)) diag.push_back(wg[k]);
+      if (!pack_diag)
+        while (diag.size() % 4) diag.push_back({0xFFFF, 0xFFFF});
     }
   }
+  // the blocks of the diagonal tiles follow the off-diagonal tiles, four to a workgroup
+  for (const ngd_tile &j : diag) jobs.push_back(j);
+  while (jobs.size() % 4) jobs.push_back({0xFFFF, 0xFFFF});
   e->n_wg = (uint32_t)(jobs.size() / 4);
   if (kernel == NGD_KERNEL_STREAM && world > 1) {
     for (const ngd_tile &t : tiles)
