@@ -220,7 +220,18 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   std::vector<ngd_tile> jobs, diag;
   auto live = [&](uint16_t r, uint16_t c) { return (uint64_t)r * 16 < g.n_ind && (uint64_t)c * 16 < g.n_ind; };
   const bool pack_diag = env_u64("NGD_MFMA_PACK_DIAG", 1) != 0;
-  for (const ngd_tile &t : tiles) {
+  std::vector<ngd_tile> order = tiles;
+  switch (env_u64("NGD_MFMA_ORDER", 0)) {
+    case 1:  // column-major
+      std::stable_sort(order.begin(), order.end(), [](const ngd_tile &a, const ngd_tile &b) { return a.tj < b.tj; });
+      break;
+    case 2:  // by anti-diagonal distance tj - ti
+      std::stable_sort(order.begin(), order.end(),
+                       [](const ngd_tile &a, const ngd_tile &b) { return a.tj - a.ti < b.tj - b.ti; });
+      break;
+    default: break;  // row-major
+  }
+  for (const ngd_tile &t : order) {
     const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
     ngd_tile wg[4];
     if (t.ti != t.tj) {
@@ -308,7 +319,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     uint64_t want = env_u64("NGD_MFMA_WG", 8192);
     const uint32_t wg_per_slice = std::max(1u, e->n_wg);
     uint64_t ks = (want + wg_per_slice - 1) / wg_per_slice;
-    uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 64));
+    uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 128));
     ks = std::min(ks, max_ks);
     ks = env_u64("NGD_MFMA_KS", ks);
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
