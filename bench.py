@@ -97,7 +97,7 @@ def main():
     d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
     h_sum = torch.empty(n_pairs, dtype=torch.float64).pin_memory()
-    h_cnt = torch.empty(n_pairs, dtype=torch.int64).pin_memory()
+    torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
     # bootstrap workloads: replicate r>0 draws its block map from the reference's taus stream
     n_mat = W["n_boot"] + 1
@@ -105,6 +105,8 @@ def main():
     rng = N.Taus(12345)
     maps = [None] + [rng.block_map(n_eff // W["block"]) for _ in range(W["n_boot"])]
 
+    cnt_full = np.full(n_pairs, n_sites, dtype=np.uint64)
+    cnt_boot = np.full(n_pairs, n_eff, dtype=np.uint64)
     acc_ms, red_ms, tot_ms, pair_sites = [], [], [], []
     last = {}
 
@@ -128,10 +130,10 @@ def main():
                 h_sum.copy_(d_sum)
                 merge_shards(h_sum, None, dst=0)
             if rank == 0:
-                h_cnt.fill_(n_eff if maps[rep] is not None else n_sites)
+                cnt_np = cnt_boot if maps[rep] is not None else cnt_full
             if rank == 0:
                 with np.errstate(all="ignore"):
-                    last["dist"] = N.finish(h_sum.numpy(), h_cnt.numpy().view(np.uint64), 0, W["evol_model"])
+                    last["dist"] = N.finish(h_sum.numpy(), cnt_np, 0, W["evol_model"])
 
     def fence():
         if world > 1:

@@ -35,8 +35,7 @@ struct ngd_engine {
   ngd_score sc{};
   int device = 0;
   int kernel = 0;  // resolved NGD_KERNEL_*
-  hipStream_t st = nullptr, st2 = nullptr;  // st2: the diagonal-block launch of the MFMA kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t st = nullptr;
   hipEvent_t ev[5] = {};
   // resident data set
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
@@ -123,9 +122,6 @@ void ngd_destroy(ngd_engine *e) {
   if (e->d_nan) hipFree(e->d_nan);
   for (auto &v : e->ev)
     if (v) hipEventDestroy(v);
-  if (e->ev_fork) hipEventDestroy(e->ev_fork);
-  if (e->ev_join) hipEventDestroy(e->ev_join);
-  if (e->st2) hipStreamDestroy(e->st2);
   if (e->st) hipStreamDestroy(e->st);
   delete e;
 }
@@ -187,13 +183,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   };
   if (hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(NGD_E_HIP, "ngd_create: hipStreamCreate failed"));
-  if (hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking) != hipSuccess)
-    return bail(fail(NGD_E_HIP, "ngd_create: hipStreamCreate failed"));
   for (auto &v : e->ev)
     if (hipEventCreate(&v) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
-  if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)
-    return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
 
   // ---- shard: upper-triangular 128-tiles dealt by cost over ranks (ngd_shard.h) ----
   std::vector<ngd_tile> tiles, tiles16;
