@@ -86,7 +86,7 @@ int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_
   if (!sum || !cnt || !dist) return NGD_E_INVALID;
   // per-cell and order-free, so threads change nothing but the wall time
   unsigned nt = 1;
-  if (n_pairs >= (1u << 16)) nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n_pairs >= (1u << 16)) nt = std::min(n_pairs >= (1u << 18) ? 16u : 8u, std::max(1u, std::thread::hardware_concurrency()));
   if (nt <= 1) {
     finish_range(sum, cnt, 0, n_pairs, tot_sites, evol_model, dist);
   } else {

@@ -156,3 +156,48 @@ def test_nan_in_binary_input_is_the_reference_error(tmp_path):
         r = subprocess.run([BIN, "--geno", str(bad), "--probs", "--n_ind", "6", "--n_sites", "200", "--out",
                             str(tmp_path / "o"), "--verbose", "0", "--prep", prep], capture_output=True)
         assert r.returncode == 255 and b"NaN found! Is the file format correct?" in r.stderr
+
+
+def test_text_input_edges_empty_line_header_extra_columns(tmp_path):
+    """read_data.cpp:48-103: an empty line keeps the site at its fill, a short first line is a header,
+    non-numeric fields are dropped, only the LAST n_ind*n_geno columns are used."""
+    n_ind, n_sites = 5, 12
+    rng = np.random.default_rng(2)
+    g = rng.integers(-1, 3, size=(n_sites, n_ind))
+    path = tmp_path / "edges.geno.gz"
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("chr\tpos\n")  # header: fewer numeric fields than n_ind
+        for s in range(n_sites):
+            if s == 4:
+                fh.write("\n")  # empty line
+            else:
+                fh.write("chrX\t%d\tNA\t7\t" % s + " ".join(str(int(x)) for x in g[s]) + "\n")
+    p = O.load_text(str(path), n_ind, n_sites, in_probs=False)
+    assert np.all(p[:, 4, :] == 0.0)
+    for extra, kw in (([], {}), (["--pairwise_del"], dict(pairwise_del=True)), (["--evol_model", "0"], dict(evol_model=0))):
+        exp = O.run_reference_flow(p, **kw)
+        assert cli(tmp_path, "--geno", path, "--n_ind", n_ind, "--n_sites", n_sites, *extra) == exp
+
+
+def test_text_input_errors(tmp_path):
+    path = tmp_path / "short.geno.gz"
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("0\t1\t2\n0\t1\n")  # second line: less fields than expected
+    r = subprocess.run([BIN, "--geno", str(path), "--n_ind", "3", "--n_sites", "2", "--out", str(tmp_path / "o"),
+                        "--verbose", "0"], capture_output=True)
+    assert r.returncode == 255 and b"Less fields than expected!" in r.stderr
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("0\t1\t2\n")
+    r = subprocess.run([BIN, "--geno", str(path), "--n_ind", "3", "--n_sites", "2", "--out", str(tmp_path / "o"),
+                        "--verbose", "0"], capture_output=True)
+    assert r.returncode == 255 and b"premature EOF" in r.stderr
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("0\t1\t2\n0\t1\t2\n0\t1\t2\n")
+    r = subprocess.run([BIN, "--geno", str(path), "--n_ind", "3", "--n_sites", "2", "--out", str(tmp_path / "o"),
+                        "--verbose", "0"], capture_output=True)
+    assert r.returncode == 255 and b"not at EOF" in r.stderr
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("0\t1\t3\n0\t1\t2\n")
+    r = subprocess.run([BIN, "--geno", str(path), "--n_ind", "3", "--n_sites", "2", "--out", str(tmp_path / "o"),
+                        "--verbose", "0"], capture_output=True)
+    assert r.returncode == 255 and b"Genotypes must be coded as {-1,0,1,2}" in r.stderr

@@ -301,3 +301,36 @@ def test_device_prep_reports_nan_like_the_reference():
     with N().Engine(6, 100) as e:
         with pytest.raises(N().NgdError):
             e.upload_raw_sites(raw, 0, call_geno=True, N_thresh=0.9, call_thresh=0.5)
+
+
+# ---- geometry edges: tile boundaries, many tiles, tiny inputs --------------------------------------
+@pytest.mark.parametrize("n_ind,n_sites", [(129, 300), (385, 200), (1300, 128), (64, 15), (65, 17), (128, 4)])
+def test_tile_boundaries_and_many_tiles(n_ind, n_sites):
+    p = O.synth_indmajor(41, n_ind, n_sites, miss_frac=0.1)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    s, c = gpu_pairs(p, "mfma", pairwise_del=True)
+    assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+    if n_ind <= 400:
+        s, c = gpu_pairs(p, "em_fast", pairwise_del=True, indep_geno=False)
+        so, co = O.all_pairs(p, pairwise_del=True, indep_geno=False, n_threads=8)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
+def test_all_zero_site_vectors_count_and_contribute_nothing():
+    """an empty text line leaves (0,0,0): it counts as a site without --pairwise_del and is
+    'missing' with it; under EM it makes the pair NaN exactly as on the CPU."""
+    p = O.synth_indmajor(3, 9, 64)
+    p[2, 10] = 0.0
+    p[5, 10] = 0.0
+    p[5, 40] = 0.0
+    for pd in (False, True):
+        s, c = gpu_pairs(p, "mfma", pairwise_del=pd)
+        so, co = O.all_pairs(p, pairwise_del=pd)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        for k in ("em_fast", "em_faithful"):
+            s, c = gpu_pairs(p, k, pairwise_del=pd, indep_geno=False)
+            so, co = O.all_pairs(p, pairwise_del=pd, indep_geno=False)
+            assert np.array_equal(c, co)
+            assert np.array_equal(np.isnan(s), np.isnan(so))
+            ok = ~np.isnan(so)
+            assert rel_err(s[ok], so[ok]) < RTOL
