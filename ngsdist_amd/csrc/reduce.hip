@@ -7,7 +7,9 @@
 
 namespace {
 
-// grid = owned 128-tiles x 128 rows; 128 threads = columns.
+// grid = owned 128-tiles x 128 rows; 128 threads = columns.  Eight interleaved partial sums (slice
+// ks goes to partial ks % 8) keep eight loads in flight per thread; they are combined in a fixed tree,
+// so the result is a fixed function of the slabs (deterministic), just not the left-to-right sum.
 __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab, uint32_t n_ks,
                                                  const ngd_tile *__restrict__ tiles, uint32_t n_pad,
                                                  uint64_t n_ind, double *__restrict__ d_sum) {
@@ -17,9 +19,14 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
   if (!(i < j && j < n_ind)) return;
   const uint64_t plane = (uint64_t)n_pad * n_pad;
   const double *p = slab + (uint64_t)i * n_pad + j;
-  double s = 0;
-  for (uint32_t ks = 0; ks < n_ks; ks++) s += p[ks * plane];  // ascending slices: deterministic
-  d_sum[ngd_pair_idx(n_ind, i, j)] = s;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t ks = 0;
+  for (; ks + 8 <= n_ks; ks += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) s[u] += p[(uint64_t)(ks + u) * plane];
+  }
+  for (int u = 0; ks < n_ks; ks++, u++) s[u] += p[(uint64_t)ks * plane];
+  d_sum[ngd_pair_idx(n_ind, i, j)] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // Bootstrap replicate from per-block partial sums: sum = SUM_slice w[slice] * slab[slice], slices in
