@@ -13,11 +13,10 @@
 //
 // Wavefront  = one JOB = a 64x64 block of pairs = 4x4 MFMA tiles, 16 accumulators of 4 doubles.
 // Workgroup  = 4 jobs x one slice of k.  The four jobs of an off-diagonal 128x128 tile share a
-// workgroup (their operands overlap); a diagonal tile gives one full job and two jobs ON the
-// diagonal, whose MFMA pattern is the upper triangle only (10 of 16 tiles) -- same launch, same
-// slice, so their rows are read while the off-diagonal jobs of that slice have them in L2 (as a
-// separate launch the diagonal jobs re-streamed the whole data set: 49 GB for 8 % of the flops).
-// Job lists are built by the engine (engine.hip).
+// workgroup (their operands overlap); the blocks of the diagonal tiles follow, packed four to a
+// workgroup -- same launch, same slice, so their rows are read while the off-diagonal jobs of that
+// slice have them in L2 (as a separate launch the diagonal jobs re-streamed the whole data set:
+// 49 GB for 8 % of the flops).  Job lists are built by the engine (engine.hip).
 // Operands come straight from the fragment-major images (ngd_internal.h): one
 // coalesced 512-B global load per 16x4 operand, software-pipelined DEPTH k-groups
 // ahead in registers; the 4 wavefronts of a tile share operands through L1/L2.
@@ -39,11 +38,22 @@ constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
 // profiles/r01_fp64_peak_microbench.txt); the 64-cycle pipe rate needs two
 // wavefronts per SIMD that are BOTH in their MFMA phase, so a third resident
 // wavefront is what covers the others' load/wait/epilogue phases.
-// TRI_JOBS: build the triangular pattern for blocks on the diagonal (else they run the full one)
-template <bool WEIGHTED, int DEPTH, int WPS, bool TRI_JOBS>
+// one operand fragment: 512 B for the wavefront, lane l takes bytes [8l, 8l+8) at base + OFF
+template <int OFF>
+__device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const double *base) {
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(lane_off), "s"(base), "n"(OFF));
+}
+
+// EXACT: build one code path per block shape (rows x cols MFMA tiles, triangular on the diagonal) so
+// that no MFMA is issued for padding or for the lower triangle; otherwise every block runs the full
+// 4x4 pattern.  EXACT is for small n_ind, where up to half of a 64x64 block grid is padding: blocks of
+// different shapes progress at different rates through k, which costs the L2 residency that large
+// n_ind depends on (measured: 45.5 -> 51.8 ms at n_ind = 1000) but nothing when the whole operand
+// panel of a slice is a few tens of KB.
+template <bool WEIGHTED, int DEPTH, int WPS, bool EXACT>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
-    const ngd_tile *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
+    const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
@@ -52,11 +62,12 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
   // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const ngd_tile job = jobs[tile * 4 + wave];  // first row / column group of the 64x64 block
-  if (job.ti == 0xFFFFu) return;               // padding entry of the job list
-  // blocks ON the diagonal carry a flag: their MFMA tiles below the diagonal hold no pair i1 < i2
-  const bool tri = __builtin_amdgcn_readfirstlane(job.tj >> 15) != 0;
-  const uint32_t ig0 = job.ti, jg0 = job.tj & 0x7FFFu;
+  const ngd_job job = jobs[tile * (blockDim.x >> 6) + wave];  // 4 jobs per workgroup, or 1 (EXACT)
+  if (job.rows == 0) return;  // padding entry of the job list
+  const uint32_t ig0 = job.ig0, jg0 = job.jg0;
+  // shape code, wave-uniform: rows | cols << 3 | tri << 6
+  const uint32_t shape = __builtin_amdgcn_readfirstlane((uint32_t)job.rows | ((uint32_t)job.cols << 3) |
+                                                        ((uint32_t)job.tri << 6));
 
   const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
@@ -73,10 +84,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const double *pb = QB + (uint64_t)jg0 * 64;
   const uint32_t lane_off = lane * 8;
 
-  double a[DEPTH][WM], bq[DEPTH][WN];
-  uint32_t wq[DEPTH];
+  constexpr int RING = DEPTH;
+  double a[RING][WM], bq[RING][WN];
+  uint32_t wq[RING];
 #pragma unroll
-  for (int d = 0; d < DEPTH; d++) wq[d] = 0;
+  for (int d = 0; d < RING; d++) wq[d] = 0;
 
   // The operand pipeline is issued by hand.  hipcc's waitcnt pass puts a full
   // `s_waitcnt vmcnt(0)` at the head of any loop whose loads are consumed one
@@ -126,7 +138,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   // two instantiations must not share a control-flow join while loads are in flight: the asm loads
   // are invisible to the compiler, so a register copy it placed at such a join would read a
   // register the load has not written yet.
-  auto run = [&](auto tri_c) {
+  auto run = [&](auto rows_c, auto cols_c, auto tri_c) {
+    constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value;
     constexpr bool TRI = decltype(tri_c)::value;
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch(d, kg0 + d);
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
           for (int m = 0; m < WM; m++)
 #pragma unroll
             for (int n = 0; n < WN; n++)
-              if (!TRI || m <= n)
+              if (m < PM && n < PN && (!TRI || m <= n))
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
@@ -155,9 +168,86 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
     __builtin_amdgcn_sched_barrier(0);
   };
+  // The same unit for a block of PM x PN MFMA tiles (upper triangle if TRI) with a D-deep ring: only
+  // the PM + PN operand fragments it needs are loaded.  (Deeper rings for the narrow shapes were tried:
+  // D = 2 and 4 lose 10-20 % to D = 1 at n_ind = 200..300.)
+  auto run_exact = [&](auto rows_c, auto cols_c, auto tri_c, auto depth_c) {
+    constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value, D = decltype(depth_c)::value;
+    constexpr bool TRI = decltype(tri_c)::value;
+    constexpr int LOADS = PM + PN + (WEIGHTED ? 1 : 0);
+    auto fetch_x = [&](int d, uint64_t kg) {
+      const double *xa = pa + kg * kstride;
+      const double *xb = pb + kg * kstride;
+      if (PM > 0) load_frag<0>(a[d][0], lane_off, xa);
+      if (PM > 1) load_frag<512>(a[d][1], lane_off, xa);
+      if (PM > 2) load_frag<1024>(a[d][2], lane_off, xa);
+      if (PM > 3) load_frag<1536>(a[d][3], lane_off, xa);
+      if (PN > 0) load_frag<0>(bq[d][0], lane_off, xb);
+      if (PN > 1) load_frag<512>(bq[d][1], lane_off, xb);
+      if (PN > 2) load_frag<1024>(bq[d][2], lane_off, xb);
+      if (PN > 3) load_frag<1536>(bq[d][3], lane_off, xb);
+      if (WEIGHTED) {
+        const uint32_t *xw = ws + (kg * 4 + (uint64_t)(lane >> 4)) / 3;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(wq[d]) : "v"(xw));
+      }
+    };
+    auto arrive_x = [&](int d) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (D - 1)) : "memory");
+#pragma unroll
+      for (int m = 0; m < PM; m++) asm volatile("" : "+v"(a[d][m]));  // pins the MFMAs behind the wait
+#pragma unroll
+      for (int n = 0; n < PN; n++) asm volatile("" : "+v"(bq[d][n]));
+      if (WEIGHTED) asm volatile("" : "+v"(wq[d]));
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch_x(d, kg0 + d);
+    for (uint64_t kg = kg0; kg < kg1; kg += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        arrive_x(d);
+        if (D == 1 || kg + d < kg1) {
+          if (WEIGHTED) {
+            const double w = (double)wq[d];
+#pragma unroll
+            for (int m = 0; m < PM; m++) a[d][m] *= w;
+          }
+#pragma unroll
+          for (int m = 0; m < PM; m++)
+#pragma unroll
+            for (int n = 0; n < PN; n++)
+              if (!TRI || m <= n)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_x(d, kg + d + D);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using std::integral_constant;
+  typedef integral_constant<int, 1> I1;
+  typedef integral_constant<int, 2> I2;
+  typedef integral_constant<int, 3> I3;
+  typedef integral_constant<int, 4> I4;
 
   if (kg0 < kg1) {
-    if (TRI_JOBS && tri) run(std::true_type{}); else run(std::false_type{});
+    if (!EXACT) {
+      run(I4{}, I4{}, std::false_type{});
+    } else {
+      switch (shape) {  // rows | cols << 3 | tri << 6
+        case 4 | 4 << 3: run(I4{}, I4{}, std::false_type{}); break;
+        case 4 | 3 << 3: run_exact(I4{}, I3{}, std::false_type{}, I1{}); break;
+        case 4 | 2 << 3: run_exact(I4{}, I2{}, std::false_type{}, I1{}); break;
+        case 4 | 1 << 3: run_exact(I4{}, I1{}, std::false_type{}, I1{}); break;
+        case 4 | 4 << 3 | 1 << 6: run_exact(I4{}, I4{}, std::true_type{}, I1{}); break;
+        case 3 | 3 << 3 | 1 << 6: run_exact(I3{}, I3{}, std::true_type{}, I1{}); break;
+        case 2 | 2 << 3 | 1 << 6: run_exact(I2{}, I2{}, std::true_type{}, I1{}); break;
+        case 1 | 1 << 3 | 1 << 6: run_exact(I1{}, I1{}, std::true_type{}, I1{}); break;
+        default: run(I4{}, I4{}, std::false_type{});  // any other shape: the full pattern is always right
+      }
+    }
   }
 
   // D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*r
@@ -168,7 +258,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     for (int n = 0; n < WN; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (TRI_JOBS && tri && m > n) continue;
+        if (EXACT && (m >= (int)(shape & 7) || n >= (int)((shape >> 3) & 7) || ((shape >> 6) && m > n))) continue;
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
         out[(uint64_t)i * n_pad + j] = acc[m][n][r];
@@ -178,35 +268,29 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 }  // namespace
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, uint32_t n_ks,
-                           uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
+                           const uint32_t *d_ws, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
+                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
   if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)
   static const int variant = [] {
     const char *v = getenv("NGD_MFMA_VARIANT");
     return v && *v ? atoi(v) : 0;
   }();
-  static const int tri_jobs = [] {
-    const char *v = getenv("NGD_MFMA_TRI");
-    return v && *v ? atoi(v) : 0;
-  }();
-#define NGD_MFMA(W, D, P)                                                                                    \
-  do {                                                                                                       \
-    if (tri_jobs)                                                                                            \
-      hipLaunchKernelGGL((k_accum_mfma<W, D, P, true>), dim3(n_wg * n_ks), dim3(256), 0, st, PA, QB, d_ws,    \
-                         d_jobs, n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);                       \
-    else                                                                                                     \
-      hipLaunchKernelGGL((k_accum_mfma<W, D, P, false>), dim3(n_wg * n_ks), dim3(256), 0, st, PA, QB, d_ws,   \
-                         d_jobs, n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab);                       \
-  } while (0)
+  // EXACT: one job per (single-wavefront) workgroup -- jobs of different shapes last differently, and a
+  // wavefront that is done should not wait for three siblings before its slot is handed on
+#define NGD_MFMA(W, D, P, X)                                                                                    \
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_jobs, \
+                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
   // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
   // (profiles/r01_*): the third wavefront covers the others' load phases.
   // variant 1: 4-deep register ring, 2 wavefronts per SIMD.
   // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
-  if (d_ws) {
-    if (variant == 1) NGD_MFMA(true, 4, 2); else NGD_MFMA(true, 1, 3);
+  if (exact_shapes) {
+    if (d_ws) NGD_MFMA(true, 1, 3, true); else NGD_MFMA(false, 1, 3, true);
+  } else if (d_ws) {
+    if (variant == 1) NGD_MFMA(true, 4, 2, false); else NGD_MFMA(true, 1, 3, false);
   } else {
-    if (variant == 1) NGD_MFMA(false, 4, 2); else NGD_MFMA(false, 1, 3);
+    if (variant == 1) NGD_MFMA(false, 4, 2, false); else NGD_MFMA(false, 1, 3, false);
   }
 #undef NGD_MFMA
 }

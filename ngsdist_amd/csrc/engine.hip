@@ -48,8 +48,9 @@ struct ngd_engine {
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
   uint32_t n_tiles = 0, n_tiles16 = 0;
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
-  ngd_tile *d_jobs = nullptr, *d_jobs_tri = nullptr;
-  uint32_t n_wg = 0, n_wg_tri = 0;
+  ngd_job *d_jobs = nullptr;
+  uint32_t n_wg = 0;
+  int exact_shapes = 0;  // small n_ind: one code path per block shape (accum_mfma.hip EXACT)
   uint64_t *d_pairs = nullptr;
   uint64_t n_owned_pairs = 0;
   // scratch + results
@@ -110,7 +111,7 @@ void ngd_destroy(ngd_engine *e) {
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_block_map, e->d_mult, e->d_ws,
-                  e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->d_jobs_tri, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
+                  e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -205,47 +206,49 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     }
   e->n_tiles = (uint32_t)tiles.size();
   e->n_tiles16 = (uint32_t)tiles16.size();
-  // job list of the MFMA kernel (units: 16-individual groups; bit 15 of tj = block on the diagonal).
-  // Off-diagonal tile -> its four 64x64 blocks in one workgroup; diagonal tile -> its upper-right
-  // block and its two diagonal blocks (+ one empty slot) in one workgroup.
-  std::vector<ngd_tile> jobs, diag;
-  auto live = [&](uint16_t r, uint16_t c) { return (uint64_t)r * 16 < g.n_ind && (uint64_t)c * 16 < g.n_ind; };
-  const bool pack_diag = env_u64("NGD_MFMA_PACK_DIAG", 1) != 0;
-  std::vector<ngd_tile> order = tiles;
-  switch (env_u64("NGD_MFMA_ORDER", 0)) {
-    case 1:  // column-major
-      std::stable_sort(order.begin(), order.end(), [](const ngd_tile &a, const ngd_tile &b) { return a.tj < b.tj; });
-      break;
-    case 2:  // by anti-diagonal distance tj - ti
-      std::stable_sort(order.begin(), order.end(),
-                       [](const ngd_tile &a, const ngd_tile &b) { return a.tj - a.ti < b.tj - b.ti; });
-      break;
-    default: break;  // row-major
-  }
-  for (const ngd_tile &t : order) {
-    const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
-    ngd_tile wg[4];
-    if (t.ti != t.tj) {
-      for (uint16_t a = 0; a < 2; a++)
-        for (uint16_t b = 0; b < 2; b++) wg[2 * a + b] = {(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b)};
-      for (ngd_tile &j : wg) {
-        if (!live(j.ti, j.tj)) j = {0xFFFF, 0xFFFF};  // only padding individuals
-        jobs.push_back(j);
+  // job list of the MFMA kernel (ngd_job, units of 16 individuals).
+  std::vector<ngd_job> jobs;
+  const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);  // groups that hold at least one individual
+  e->exact_shapes = env_u64("NGD_MFMA_EXACT", g.n_pad <= env_u64("NGD_MFMA_EXACT_MAX_PAD", 384) ? 1 : 0) != 0;
+  if (e->exact_shapes) {
+    // blocks of up to 4 x 4 groups over the valid groups only; the last block row / column is narrower,
+    // blocks on the diagonal are triangular.  Most expensive first, four to a workgroup.
+    const uint32_t nb = (n_igv + 3) / 4;
+    for (uint32_t bi = 0; bi < nb; bi++)
+      for (uint32_t bj = bi; bj < nb; bj++) {
+        if (owner[ngd_tile_id(g.n_t, bi / 2, bj / 2)] != cfg->shard_rank) continue;
+        const uint8_t r = (uint8_t)std::min(4u, n_igv - 4 * bi), c = (uint8_t)std::min(4u, n_igv - 4 * bj);
+        jobs.push_back({(uint16_t)(4 * bi), (uint16_t)(4 * bj), r, c, (uint8_t)(bi == bj), 0});
       }
-    } else {
-      wg[0] = {r0, (uint16_t)(c0 | 0x8000)};
-      wg[1] = {r0, (uint16_t)(c0 + 4)};
-      wg[2] = {(uint16_t)(r0 + 4), (uint16_t)((c0 + 4) | 0x8000)};
-      for (int k = 0; k < 3; k++)
-        if (live(wg[k].ti, wg[k].tj & 0x7FFF)) diag.push_back(wg[k]);
-      if (!pack_diag)
-        while (diag.size() % 4) diag.push_back({0xFFFF, 0xFFFF});
+    auto cost = [](const ngd_job &j) { return j.tri ? j.rows * (j.rows + 1) / 2 : j.rows * j.cols; };
+    std::stable_sort(jobs.begin(), jobs.end(), [&](const ngd_job &a, const ngd_job &b) { return cost(a) > cost(b); });
+  } else {
+    // Off-diagonal 128-tile -> its four 64x64 blocks in one workgroup (they share operands); the blocks of
+    // the diagonal tiles (two on the diagonal, one above it) follow, packed four to a workgroup.  Every
+    // block runs the full 4x4 pattern, so all workgroups of a slice progress at one rate.
+    std::vector<ngd_job> diag;
+    auto live = [&](uint32_t r, uint32_t c) { return r < n_igv && c < n_igv; };
+    for (const ngd_tile &t : tiles) {
+      const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
+      if (t.ti != t.tj) {
+        for (uint16_t a = 0; a < 2; a++)
+          for (uint16_t b = 0; b < 2; b++) {
+            ngd_job j = {(uint16_t)(r0 + 4 * a), (uint16_t)(c0 + 4 * b), 4, 4, 0, 0};
+            if (!live(j.ig0, j.jg0)) j.rows = 0;  // only padding individuals
+            jobs.push_back(j);
+          }
+      } else {
+        const ngd_job d[3] = {{r0, c0, 4, 4, 1, 0}, {r0, (uint16_t)(c0 + 4), 4, 4, 0, 0},
+                              {(uint16_t)(r0 + 4), (uint16_t)(c0 + 4), 4, 4, 1, 0}};
+        for (const ngd_job &j : d)
+          if (live(j.ig0, j.jg0)) diag.push_back(j);
+      }
     }
+    for (const ngd_job &j : diag) jobs.push_back(j);
   }
-  // the blocks of the diagonal tiles follow the off-diagonal tiles, four to a workgroup
-  for (const ngd_tile &j : diag) jobs.push_back(j);
-  while (jobs.size() % 4) jobs.push_back({0xFFFF, 0xFFFF});
-  e->n_wg = (uint32_t)(jobs.size() / 4);
+  const uint32_t jobs_per_wg = e->exact_shapes ? 1 : 4;
+  while (jobs.size() % jobs_per_wg) jobs.push_back({0, 0, 0, 0, 0, 0});
+  e->n_wg = (uint32_t)(jobs.size() / jobs_per_wg);
   if (kernel == NGD_KERNEL_STREAM && world > 1) {
     for (const ngd_tile &t : tiles)
       for (uint64_t i = (uint64_t)t.ti * NGD_TILE; i < std::min<uint64_t>(g.n_ind, (t.ti + 1ull) * NGD_TILE); i++)
@@ -277,7 +280,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
   TRY(dev_alloc(e, &e->d_jobs, jobs.size(), false));
   if (!jobs.empty())
-    if (hipMemcpy(e->d_jobs, jobs.data(), jobs.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(e->d_jobs, jobs.data(), jobs.size() * sizeof(ngd_job), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(NGD_E_HIP, "ngd_create: job list upload failed"));
 
   if (!tiles.empty())
@@ -309,7 +312,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (kernel == NGD_KERNEL_MFMA) {
     uint64_t want = env_u64("NGD_MFMA_WG", 8192);
     const uint32_t wg_per_slice = std::max(1u, e->n_wg);
-    uint64_t ks = (want + wg_per_slice - 1) / wg_per_slice;
+    uint64_t ks = (want * (e->exact_shapes ? 4 : 1) + wg_per_slice - 1) / wg_per_slice;  // EXACT: 1-wave workgroups
     uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 128));
     ks = std::min(ks, max_ks);
     ks = env_u64("NGD_MFMA_KS", ks);
@@ -513,7 +516,8 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
         if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
           ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
         else
-          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, n_ks, per_slice, kg_lim, slab);
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
+                                kg_lim, slab);
         break;
       default:
         ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -532,7 +536,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
     if (!mfma || block_size % 4 == 0) {
       // split large blocks so that there are enough workgroups; slices of one block share its weight
       const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
-      const uint32_t tiles_n = mfma ? e->n_wg : e->n_tiles16;
+      const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1)) : e->n_tiles16;
       uint64_t sub = 1;
       const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
       while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)

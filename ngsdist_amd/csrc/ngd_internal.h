@@ -57,6 +57,14 @@ struct ngd_tile {
   uint16_t ti, tj;  // tile coordinates (units depend on the list: 128 or 16 individuals)
 };
 
+// One wavefront's work in the MFMA kernel: the block of pairs whose first row / column groups (of 16
+// individuals) are ig0 / jg0, rows x cols MFMA tiles (1..4 each), upper triangle only if tri.
+// rows == 0 marks a padding entry of the list.
+struct ngd_job {
+  uint16_t ig0, jg0;
+  uint8_t rows, cols, tri, pad;
+};
+
 // ---- kernel launchers (each in its own .hip file) -------------------------
 // layout.hip
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
@@ -81,8 +89,8 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
 
 // accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_tile *d_jobs, uint32_t n_wg, uint32_t n_ks,
-                           uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
+                           const uint32_t *d_ws, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
+                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
 
 // accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
 void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
