@@ -514,7 +514,9 @@ int main(int argc, char **argv) {
   // engines: pair tiles dealt over --n_gpus devices, input replicated
   int n_dev = ngd_device_count();
   if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
-  if (p.device + p.n_gpus > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
+  // NGD_HOST_SAME_DEVICE=1: every shard on --device (rehearses the multi-GPU merge on a 1-GPU box)
+  const bool same_device = getenv("NGD_HOST_SAME_DEVICE") && atoi(getenv("NGD_HOST_SAME_DEVICE")) != 0;
+  if (p.device + (same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
   Engines eng;
   for (int r = 0; r < p.n_gpus; r++) {
     ngd_config cfg;
@@ -524,7 +526,7 @@ int main(int argc, char **argv) {
     memcpy(cfg.score, p.score, sizeof(cfg.score));
     cfg.pairwise_del = p.pairwise_del;
     cfg.indep_geno = p.indep_geno;
-    cfg.device = p.device + r;
+    cfg.device = same_device ? p.device : p.device + r;
     cfg.kernel = p.kernel;
     cfg.shard_rank = (uint32_t)r;
     cfg.shard_world = (uint32_t)p.n_gpus;

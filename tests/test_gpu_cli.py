@@ -201,3 +201,42 @@ def test_text_input_errors(tmp_path):
     r = subprocess.run([BIN, "--geno", str(path), "--n_ind", "3", "--n_sites", "2", "--out", str(tmp_path / "o"),
                         "--verbose", "0"], capture_output=True)
     assert r.returncode == 255 and b"Genotypes must be coded as {-1,0,1,2}" in r.stderr
+
+
+def test_multi_gpu_merge_path_on_one_device(tmp_path, monkeypatch):
+    """--n_gpus 3 with every shard on device 0: three engines, pair tiles dealt over them, sums merged on
+    the host -- the same bytes as one engine."""
+    monkeypatch.setenv("NGD_HOST_SAME_DEVICE", "1")
+    n_ind, n_sites = 300, 500
+    raw = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.1).transpose(1, 0, 2).copy()
+    path = tmp_path / "g.bin"
+    raw.tofile(str(path))
+    base = ["--geno", path, "--probs", "--n_ind", n_ind, "--n_sites", n_sites]
+    for extra in (["--indep_geno", "--pairwise_del"], ["--evol_model", "2"],
+                  ["--indep_geno", "--n_boot_rep", "2", "--boot_block_size", "20", "--seed", "3"]):
+        one = cli(tmp_path, *base, *extra, name="one.dist")
+        three = cli(tmp_path, *base, *extra, "--n_gpus", 3, name="three.dist")
+        assert one == three
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the fields the driver reads."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2", "--n_sites", "4000",
+                        "--steps", "2", "--warmup", "1", "--cpu_sites", "400"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port"
+    assert d["spot_check"]["max_rel_err_vs_oracle"] < 1e-9
