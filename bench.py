@@ -179,20 +179,22 @@ def main():
     cpu = None
     try:
         from oracle import oracle as O
-        if W["indep"] and maps[-1] is None:
-            idx = [0, 1, n_ind // 2, n_ind - 1]
-            sub = np.concatenate([O.synth_indmajor(W["seed"], n_ind, n_sites, i0=i, n_sub=1) for i in idx])
-            so, co = O.all_pairs(sub, indep_geno=True, n_threads=4)
-            with np.errstate(all="ignore"):
-                do = O.finish(so, co, 0, W["evol_model"])
-            k = 0
-            worst = 0.0
-            for a in range(len(idx)):
-                for b in range(a + 1, len(idx)):
-                    g = last["dist"][N.n_pairs(n_ind) - N.n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
-                    worst = max(worst, abs(g - do[k]) / abs(do[k]))
-                    k += 1
-            spot = {"pairs": k, "sites": n_sites, "max_rel_err_vs_oracle": worst}
+        # 4 individuals -> 6 pairs, every site of the LAST matrix of the step (full data or last replicate)
+        idx = [0, 1, n_ind // 2, n_ind - 1]
+        sub = np.concatenate([O.synth_indmajor(W["seed"], n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+        src = None if maps[-1] is None else O.boot_site_src(maps[-1], W["block"])
+        so, co = O.all_pairs(sub, indep_geno=W["indep"], site_src=src, n_sites=n_eff if src is not None else n_sites,
+                             n_threads=6)
+        with np.errstate(all="ignore"):
+            do = O.finish(so, co, 0, W["evol_model"])
+        k = 0
+        worst = 0.0
+        for a in range(len(idx)):
+            for b in range(a + 1, len(idx)):
+                g = last["dist"][N.n_pairs(n_ind) - N.n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
+                worst = max(worst, abs(g - do[k]) / abs(do[k]))
+                k += 1
+        spot = {"pairs": k, "sites": int(n_eff if src is not None else n_sites), "max_rel_err_vs_oracle": worst}
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 figure
             cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
             rate_guess = (1.7e8 if W["indep"] else 3.0e5) * cores  # pair-sites/s per thread, measured
