@@ -1,0 +1,138 @@
+"""BASELINE.json's full sizes on the GPU.  Where the CPU oracle would take hours, parity is shown through
+(a) two independent device kernels agreeing on every pair, (b) the oracle on a few pairs over all sites,
+(c) size-independent properties of the path (additivity over site blocks, invariance under a
+permutation of the block map)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def N():
+    import ngsdist_amd
+    return ngsdist_amd
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+def test_cfg2_every_pair_against_the_oracle():
+    """configs[1]: n_ind=200, n_sites=1e5, GL, --indep_geno, model 0"""
+    n_ind, n_sites = 200, 100_000
+    p = O.synth_indmajor(2, n_ind, n_sites)
+    so, co = O.all_pairs(p, n_threads=16)
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+        s, c = e.synth_fill(2).run()
+    assert np.array_equal(c, co) and rel(s, so) < RTOL
+    d, do = N().finish(s, c, 0, 0), O.finish(so, co, 0, 0)
+    assert rel(d, do) < RTOL
+
+
+@pytest.fixture(scope="module")
+def cfg3_mfma():
+    """configs[2]: n_ind=1000, n_sites=1e6, GL, --indep_geno (51 GB resident)"""
+    e = N().Engine(1000, 1_000_000, kernel="mfma")
+    e.synth_fill(3)
+    yield e
+    e.close()
+
+
+def test_cfg3_oracle_on_a_few_pairs_over_all_sites(cfg3_mfma):
+    s, c = cfg3_mfma.run()
+    assert np.all(c == 1_000_000)
+    idx = [0, 63, 64, 127, 128, 500, 998, 999]  # block / tile edges included
+    sub = np.concatenate([O.synth_indmajor(3, 1000, 1_000_000, i0=i, n_sub=1) for i in idx])
+    so, _ = O.all_pairs(sub, n_threads=16)
+    k = 0
+    for a in range(len(idx)):
+        for b in range(a + 1, len(idx)):
+            g = s[N().n_pairs(1000) - N().n_pairs(1000 - idx[a]) + (idx[b] - idx[a] - 1)]
+            assert abs(g - so[k]) / so[k] < RTOL
+            k += 1
+    # a distance is a mean of per-site terms in [0, 1]
+    d = N().finish(s, c, 0, 0)
+    assert d.min() > 0 and d.max() < 1
+
+
+def test_cfg3_block_additivity_and_permutation_invariance(cfg3_mfma):
+    e = cfg3_mfma
+    B, nb = 1000, 1000
+    full, _ = e.run()
+    ident = np.arange(nb, dtype=np.uint64)
+    s_id, c_id = e.run(ident, B)
+    assert np.all(c_id == 1_000_000) and rel(s_id, full) < 1e-12  # same sites, different summation tree
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(ident)
+    s_perm, _ = e.run(perm, B)
+    assert np.array_equal(s_perm, s_id)  # multiplicities are what matter, not the order of the draws
+    lo = np.repeat(np.arange(nb // 2, dtype=np.uint64), 2)        # first half of the blocks, twice each
+    hi = np.repeat(np.arange(nb // 2, nb, dtype=np.uint64), 2)    # second half, twice each
+    s_lo, _ = e.run(lo, B)
+    s_hi, _ = e.run(hi, B)
+    assert rel(s_lo + s_hi, 2 * full) < 1e-12
+    # and the one-pass-per-replicate path agrees with the partial-sum path
+    import os
+    os.environ["NGD_BOOT_PARTIALS"] = "0"
+    try:
+        s_w, _ = e.run(perm, B)
+    finally:
+        os.environ.pop("NGD_BOOT_PARTIALS")
+    assert rel(s_w, s_perm) < 1e-12
+
+
+def test_cfg3_streaming_kernel_agrees_on_every_pair(cfg3_mfma):
+    """two independent device implementations (one wavefront per pair vs FP64 MFMA tiles), all 499 500 pairs"""
+    full, _ = cfg3_mfma.run()
+    with N().Engine(1000, 1_000_000, kernel="stream") as e:
+        s, c = e.synth_fill(3).run()
+    assert np.all(c == 1_000_000)
+    assert rel(s, full) < RTOL
+
+
+def test_cfg4_em_forms_agree_on_every_pair():
+    """configs[3] shape (n_ind=1000, EM, JC69) on 20 000 sites: fast form vs the form whose iterates are
+    bit-identical to emOptim2.cpp's; plus the oracle on a few pairs."""
+    n_ind, n_sites = 1000, 20_000
+    res = {}
+    for k in ("em_fast", "em_faithful"):
+        with N().Engine(n_ind, n_sites, indep_geno=False, kernel=k) as e:
+            res[k] = e.synth_fill(3).run()
+    assert np.array_equal(res["em_fast"][1], res["em_faithful"][1])
+    assert rel(res["em_fast"][0], res["em_faithful"][0]) < RTOL
+    idx = [0, 15, 16, 999]
+    sub = np.concatenate([O.synth_indmajor(3, n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+    so, co = O.all_pairs(sub, indep_geno=False, n_threads=8)
+    k = 0
+    for a in range(len(idx)):
+        for b in range(a + 1, len(idx)):
+            g = res["em_fast"][0][N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
+            assert abs(g - so[k]) / so[k] < RTOL
+            k += 1
+    with np.errstate(all="ignore"):
+        d = N().finish(res["em_fast"][0], res["em_fast"][1], 0, 2)
+    assert np.isfinite(d).all()
+
+
+def test_cfg5_bootstrap_replicates_against_the_oracle_on_a_few_pairs():
+    """configs[4]: n_ind=500, n_sites=5e5, 64 replicates of 1000-site blocks (first 3 checked)"""
+    n_ind, n_sites, B = 500, 500_000, 1000
+    rng_g, rng_o = N().Taus(12345), O.Taus(12345)
+    idx = [0, 127, 128, 499]
+    sub = np.concatenate([O.synth_indmajor(5, n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+        e.synth_fill(5)
+        for rep in range(3):
+            bm = rng_g.block_map(n_sites // B)
+            assert np.array_equal(bm, rng_o.block_map(n_sites // B))
+            s, c = e.run(bm, B)
+            so, co = O.all_pairs(sub, site_src=O.boot_site_src(bm, B), n_threads=8)
+            k = 0
+            for a in range(len(idx)):
+                for b in range(a + 1, len(idx)):
+                    pk = N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)
+                    assert c[pk] == co[k] and abs(s[pk] - so[k]) / so[k] < RTOL
+                    k += 1
