@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--shard", default="sites", choices=["sites", "pairs"],
+                    help="N>1: split the site axis (each rank holds 1/N of the data, all pairs; sums are added) "
+                         "or deal pair tiles over ranks (input replicated; disjoint results)")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,9 +93,24 @@ def main():
     if kernel == "auto":
         kernel = "mfma" if W["indep"] else "em_fast"
 
-    eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank,
-                   shard_rank=rank, shard_world=world)
-    eng.synth_fill(W["seed"], 0.0)
+    # bootstrap geometry of the WHOLE data set
+    n_mat = W["n_boot"] + 1
+    n_eff = n_sites - n_sites % W["block"]
+    by_sites = world > 1 and args.shard == "sites"
+    if by_sites:
+        # contiguous site ranges, whole bootstrap blocks and whole 16-site groups per rank
+        unit = int(np.lcm(16, W["block"]))
+        n_units = n_eff // unit
+        lo = (n_units * rank // world) * unit
+        hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
+        eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank)
+        eng.synth_fill(W["seed"], 0.0, site0=lo)
+        blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
+    else:
+        lo, hi = 0, n_sites
+        eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank,
+                       shard_rank=rank, shard_world=world)
+        eng.synth_fill(W["seed"], 0.0)
 
     d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
     d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
@@ -100,10 +118,11 @@ def main():
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
     # bootstrap workloads: replicate r>0 draws its block map from the reference's taus stream
-    n_mat = W["n_boot"] + 1
-    n_eff = n_sites - n_sites % W["block"]
     rng = N.Taus(12345)
     maps = [None] + [rng.block_map(n_eff // W["block"]) for _ in range(W["n_boot"])]
+    # site sharding: a rank needs the multiplicities of ITS blocks (ngd_run_mult)
+    mults = [None if m is None else np.bincount(m.astype(np.int64), minlength=n_eff // W["block"]).astype(np.uint32)
+             for m in maps]
 
     cnt_full = np.full(n_pairs, n_sites, dtype=np.uint64)
     cnt_boot = np.full(n_pairs, n_eff, dtype=np.uint64)
@@ -113,7 +132,10 @@ def main():
     def step(record):
         eng.drop_caches()  # bootstrap block partial sums are recomputed in every step (no carried work)
         for rep in range(n_mat):
-            eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rep], W["block"])
+            if by_sites and maps[rep] is not None:
+                eng.run_mult(mults[rep][blk_lo:blk_hi], W["block"], d_sum.data_ptr(), d_cnt.data_ptr())
+            else:
+                eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rep], W["block"])
             if record:
                 t = eng.timing()
                 red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
@@ -253,7 +275,9 @@ def main():
                                   W["evol_model"], W["n_boot"], W["block"]),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
-                   "sharding": "pair tiles dealt over %d rank(s), input replicated" % world},
+                   "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs), sums added by "
+                                "one RCCL reduce" % (world, world)) if by_sites else
+                               ("pair tiles dealt over %d rank(s), input replicated" % world)},
         "roofline": roof, "cpu_baseline": cpu, "spot_check": spot,
         "device_bytes": eng.device_bytes(),
         "ms_reduce": float(np.mean(red_ms)), "ms_engine_total": float(np.mean(tot_ms)),

@@ -126,6 +126,9 @@ int ngd_upload_raw_sites(ngd_engine *e, const double *raw, uint64_t s0, uint64_t
  * synthetic data set (bit-identical to oracle ngo_synth_one) on
  * the device, then commits.  Not part of the reference's surface. */
 int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac);
+/* Same generator, but the engine's site 0 is site `site0` of the synthetic data set: an engine
+ * that holds one contiguous range of sites (site sharding, below). */
+int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_t site0);
 
 /* One replicate = everything between rnd_map_data() and the matrix print:
  * the `for i1<i2: threadpool_add(gen_dist_slave)` + threadpool_wait block,
@@ -148,6 +151,19 @@ int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
  * engine's stream has finished. */
 int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
                    uint64_t block_size, void *d_sum, void *d_cnt);
+
+/* Site sharding.  gen_dist()'s sum and cnt are sums over sites, so a data set can also be split
+ * along the SITE axis: every engine (GPU) holds a contiguous range of sites of all individuals,
+ * computes all pairs over its range, and the per-engine (sum, cnt) are ADDED (one RCCL
+ * reduce; exact for called genotypes, <= 1e-12 relative otherwise -- the addition order differs
+ * from one engine's).  For a bootstrap replicate an engine needs the multiplicity of each of ITS
+ * blocks, which is not a block map of its own: ngd_run_mult() takes the multiplicities directly
+ * (mult[b] = number of draws of the engine's block b; ranges must be whole blocks).  cnt is then
+ * block_size * SUM mult[b] (or the multiplicity-weighted valid-site count with --pairwise_del). */
+int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size,
+                 double *sum, uint64_t *cnt);
+int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
+                        uint64_t block_size, void *d_sum, void *d_cnt);
 
 /* Bootstrap replicates re-use per-block partial sums computed on the first
  * ngd_run() that carries a block map (valid for that block size / block count;

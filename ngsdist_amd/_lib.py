@@ -47,7 +47,7 @@ class NgdTiming(C.Structure):
 EXPORTS = [
     "ngd_last_error", "ngd_abi_version", "ngd_device_count", "ngd_create", "ngd_destroy",
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
-    "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_run",
+    "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_drop_caches", "ngd_last_timing", "ngd_finish", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_shard_of_pair",
 ]
@@ -90,6 +90,9 @@ def load():
     L.ngd_stage_submit.argtypes = [vp, u64, u64, C.POINTER(NgdPrep)]
     L.ngd_upload_raw_sites.argtypes = [vp, dp, u64, u64, C.POINTER(NgdPrep)]
     L.ngd_synth_fill.argtypes = [vp, u64, C.c_double]
+    L.ngd_synth_fill_range.argtypes = [vp, u64, C.c_double, u64]
+    L.ngd_run_mult.argtypes = [vp, u32p, u64, u64, dp, u64p]
+    L.ngd_run_mult_device.argtypes = [vp, u32p, u64, u64, vp, vp]
     L.ngd_run.argtypes = [vp, u64p, u64, u64, dp, u64p]
     L.ngd_run_device.argtypes = [vp, u64p, u64, u64, vp, vp]
     L.ngd_drop_caches.argtypes = [vp]

@@ -41,7 +41,6 @@ struct ngd_engine {
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
   unsigned long long *mask = nullptr, *planes = nullptr;
   // bootstrap
-  uint64_t *d_block_map = nullptr;
   uint32_t *d_mult = nullptr, *d_ws = nullptr;
   uint64_t cap_blocks = 0;
   // shard
@@ -110,7 +109,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_block_map, e->d_mult, e->d_ws,
+  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws,
                   e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->d_wslice};
   for (void *p : ptrs)
@@ -457,17 +456,20 @@ int ngd_commit(ngd_engine *e) {
   return NGD_OK;
 }
 
-int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) {
+int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_t site0) {
   if (!e) return fail(NGD_E_INVALID, "ngd_synth_fill: null engine");
   if (e->committed) return fail(NGD_E_INVALID, "ngd_synth_fill: data set already committed");
   HIPCHK(hipSetDevice(e->device));
-  ngd_launch_synth(e->st, e->g, seed, miss_frac, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask);
+  ngd_launch_synth(e->st, e->g, seed, miss_frac, site0, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask);
   HIPCHK(hipGetLastError());
   return ngd_commit(e);
 }
 
-static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
-                    double *d_sum, unsigned long long *d_cnt) {
+int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) { return ngd_synth_fill_range(e, seed, miss_frac, 0); }
+
+// block_map != NULL: multiplicities are counted from it; else mult_in != NULL: they are given; else rep 0.
+static int run_impl(ngd_engine *e, const uint64_t *block_map, const uint32_t *mult_in, uint64_t n_blocks,
+                    uint64_t block_size, double *d_sum, unsigned long long *d_cnt) {
   if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
   if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
   HIPCHK(hipSetDevice(e->device));
@@ -476,33 +478,42 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
   uint64_t n_eff = g.n_sites;
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
+  const bool boot = block_map || mult_in;
 
   std::vector<uint32_t> mult;
+  uint64_t n_drawn = 0;  // sites visited, with multiplicity = gen_dist's cnt without --pairwise_del
   HIPCHK(hipEventRecord(e->ev[0], e->st));
-  if (block_map) {
+  if (boot) {
     if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
     if (n_blocks > g.n_sites / block_size)
       return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
     n_eff = n_blocks * block_size;
-    mult.assign(n_blocks, 0);
     uint32_t mx = 0;
-    for (uint64_t b = 0; b < n_blocks; b++) {
-      if (block_map[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
-      mx = std::max(mx, ++mult[block_map[b]]);
+    if (block_map) {
+      mult.assign(n_blocks, 0);
+      for (uint64_t b = 0; b < n_blocks; b++) {
+        if (block_map[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
+        mx = std::max(mx, ++mult[block_map[b]]);
+      }
+      n_drawn = n_eff;
+    } else {
+      mult.assign(mult_in, mult_in + n_blocks);
+      for (uint64_t b = 0; b < n_blocks; b++) {
+        mx = std::max(mx, mult[b]);
+        n_drawn += (uint64_t)mult[b] * block_size;
+      }
     }
     while (n_planes < 32 && (mx >> n_planes)) n_planes++;
     if (n_blocks > e->cap_blocks) {
-      if (e->d_block_map) { hipFree(e->d_block_map); e->dev_bytes -= e->cap_blocks * 8; }
       if (e->d_mult) { hipFree(e->d_mult); e->dev_bytes -= e->cap_blocks * 4; }
-      e->d_block_map = nullptr; e->d_mult = nullptr; e->cap_blocks = 0;
-      int rc = dev_alloc(e, &e->d_block_map, n_blocks, false);
-      if (rc) return rc;
-      rc = dev_alloc(e, &e->d_mult, n_blocks, false);
+      e->d_mult = nullptr; e->cap_blocks = 0;
+      int rc = dev_alloc(e, &e->d_mult, n_blocks, false);
       if (rc) return rc;
       e->cap_blocks = n_blocks;
     }
-    HIPCHK(hipMemcpyAsync(e->d_block_map, block_map, n_blocks * 8, hipMemcpyHostToDevice, e->st));
-    ngd_launch_weights(e->st, e->d_block_map, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws);
+    HIPCHK(hipMemcpyAsync(e->d_mult, mult.data(), n_blocks * 4, hipMemcpyHostToDevice, e->st));
+    ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws);
+    HIPCHK(hipStreamSynchronize(e->st));  // `mult` is pageable host memory
     ws = e->d_ws;
   }
 
@@ -531,7 +542,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
   // MFMA slices are whole k-groups of 4, so blocks must be multiples of 4 sites there.
   bool partials = false;
   uint32_t launches = 1;
-  if (block_map && e->kernel != NGD_KERNEL_STREAM && env_u64("NGD_BOOT_PARTIALS", 1)) {
+  if (boot && e->kernel != NGD_KERNEL_STREAM && env_u64("NGD_BOOT_PARTIALS", 1)) {
     const bool mfma = e->kernel == NGD_KERNEL_MFMA;
     if (!mfma || block_size % 4 == 0) {
       // split large blocks so that there are enough workgroups; slices of one block share its weight
@@ -602,7 +613,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
     ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles16, e->n_tiles16, d_cnt);
   } else {
-    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, n_eff, d_cnt);
+    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, boot ? n_drawn : n_eff, d_cnt);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[4], e->st));
@@ -622,13 +633,30 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks,
 int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
                    void *d_sum, void *d_cnt) {
   if (!d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_device: null output");
-  return run_impl(e, block_map, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, block_map, nullptr, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+}
+
+int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, void *d_sum,
+                        void *d_cnt) {
+  if (!d_sum || !d_cnt || !mult) return fail(NGD_E_INVALID, "ngd_run_mult_device: null argument");
+  return run_impl(e, nullptr, mult, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+}
+
+int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, double *sum,
+                 uint64_t *cnt) {
+  if (!e || !mult) return fail(NGD_E_INVALID, "ngd_run_mult: null argument");
+  int rc = run_impl(e, nullptr, mult, n_blocks, block_size, e->d_sum, e->d_cnt);
+  if (rc) return rc;
+  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
+  if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+  if (cnt) HIPCHK(hipMemcpy(cnt, e->d_cnt, n_pairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return NGD_OK;
 }
 
 int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size, double *sum,
             uint64_t *cnt) {
   if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
-  int rc = run_impl(e, block_map, n_blocks, block_size, e->d_sum, e->d_cnt);
+  int rc = run_impl(e, block_map, nullptr, n_blocks, block_size, e->d_sum, e->d_cnt);
   if (rc) return rc;
   const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
   if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));

@@ -106,12 +106,13 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 
 // Counter-based synthetic data, bit-identical to oracle ngo_synth_one().
-__global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, ngd_score sc, int pairwise_del,
-                        double *PA, double *QB, double *PI, unsigned long long *mask) {
+__global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, uint64_t site0, ngd_score sc,
+                        int pairwise_del, double *PA, double *QB, double *PI, unsigned long long *mask) {
   uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= g.n_sites * g.n_ind) return;
   uint64_t s = e / g.n_ind;
   uint32_t i = (uint32_t)(e - s * g.n_ind);
+  e += site0 * g.n_ind;  // the generator is indexed by the site's position in the WHOLE data set
   uint64_t base = seed * 0x9E3779B97F4A7C15ull;
   double x[3];
   for (int c = 0; c < 3; c++) {
@@ -127,11 +128,6 @@ __global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, ngd_score s
     if (u < miss_frac) p0 = p1 = p2 = (double)1 / 3;
   }
   emit(g, sc, pairwise_del, s, i, p0, p1, p2, PA, QB, PI, mask);
-}
-
-__global__ void k_mult(const uint64_t *__restrict__ block_map, uint64_t n_blocks, uint32_t *mult) {
-  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n_blocks) atomicAdd(&mult[block_map[b]], 1u);  // integer adds: order-independent
 }
 
 __global__ void k_expand(const uint32_t *__restrict__ mult, uint64_t n_eff, uint64_t block_size,
@@ -177,19 +173,16 @@ void ngd_launch_prep_layout(hipStream_t st, const ngd_geom &g, const double *raw
                      in_logscale, call_geno, N_thresh, call_thresh, score, pairwise_del, PA, QB, PI, mask, nan_flag);
 }
 
-void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,
+void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac, uint64_t site0,
                       const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                       unsigned long long *mask) {
   uint64_t n = g.n_sites * g.n_ind;
   hipLaunchKernelGGL(k_synth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, seed,
-                     miss_frac, score, pairwise_del, PA, QB, PI, mask);
+                     miss_frac, site0, score, pairwise_del, PA, QB, PI, mask);
 }
 
-void ngd_launch_weights(hipStream_t st, const uint64_t *d_block_map, uint64_t n_blocks,
-                        uint64_t block_size, uint64_t n_sites, uint32_t *d_mult, uint32_t *d_ws) {
-  hipMemsetAsync(d_mult, 0, n_blocks * sizeof(uint32_t), st);
-  hipLaunchKernelGGL(k_mult, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st, d_block_map,
-                     n_blocks, d_mult);
+void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
+                        const uint32_t *d_mult, uint32_t *d_ws) {
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, d_mult,
                      n_blocks * block_size, block_size, n_sites, d_ws);
 }

@@ -74,11 +74,11 @@ void ngd_launch_prep_layout(hipStream_t st, const ngd_geom &g, const double *raw
                             int in_logscale, int call_geno, double N_thresh, double call_thresh,
                             const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                             unsigned long long *mask, int *nan_flag);
-void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac,
+void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double miss_frac, uint64_t site0,
                       const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                       unsigned long long *mask);
-void ngd_launch_weights(hipStream_t st, const uint64_t *d_block_map, uint64_t n_blocks,
-                        uint64_t block_size, uint64_t n_sites, uint32_t *d_mult, uint32_t *d_ws);
+void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
+                        const uint32_t *d_mult, uint32_t *d_ws);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 

@@ -110,8 +110,9 @@ class Engine:
         _check(self._L.ngd_commit(self._h))
         return self
 
-    def synth_fill(self, seed, miss_frac=0.0):
-        _check(self._L.ngd_synth_fill(self._h, int(seed), float(miss_frac)))
+    def synth_fill(self, seed, miss_frac=0.0, site0=0):
+        """synthetic data set; site0 = position of this engine's first site in the whole set (site sharding)"""
+        _check(self._L.ngd_synth_fill_range(self._h, int(seed), float(miss_frac), int(site0)))
         return self
 
     # -- the hot path ---------------------------------------------------------
@@ -128,6 +129,20 @@ class Engine:
         c = np.empty(self.n_pairs, dtype=np.uint64)
         _check(self._L.ngd_run(self._h, ptr, nb, bs, s.ctypes.data_as(C.POINTER(C.c_double)),
                                c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return s, c
+
+    def run_mult(self, mult, block_size, d_sum_ptr=None, d_cnt_ptr=None):
+        """one replicate from the multiplicity of each of this engine's blocks (site sharding)"""
+        m = np.ascontiguousarray(mult, dtype=np.uint32)
+        mp = m.ctypes.data_as(C.POINTER(C.c_uint32))
+        if d_sum_ptr is not None:
+            _check(self._L.ngd_run_mult_device(self._h, mp, m.size, int(block_size), C.c_void_p(d_sum_ptr),
+                                               C.c_void_p(d_cnt_ptr)))
+            return None
+        s = np.empty(self.n_pairs, dtype=np.float64)
+        c = np.empty(self.n_pairs, dtype=np.uint64)
+        _check(self._L.ngd_run_mult(self._h, mp, m.size, int(block_size), s.ctypes.data_as(C.POINTER(C.c_double)),
+                                    c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
     def run_device(self, d_sum_ptr, d_cnt_ptr, block_map=None, block_size=1):

@@ -61,6 +61,48 @@ def test_two_rank_merge_is_bit_exact():
     assert n_mine > 0 and n_other > 0  # both ranks really owned something
 
 
+def _site_worker(rank, world, port, n_ind, n_sites, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from ngsdist_amd.dist import merge_shards
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # called genotypes: every term is a multiple of 0.5, so ANY split of the site axis adds up exactly
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    lo, hi = n_sites * rank // world, n_sites * (rank + 1) // world
+    s_r, c_r = O.all_pairs(np.ascontiguousarray(p[:, lo:hi]))  # stand-in for the device kernels
+    s = torch.from_numpy(s_r.copy())
+    c = torch.from_numpy(c_r.astype(np.int64))
+    merge_shards(s, c, dst=0)  # site sharding: the same collective, now a true sum
+    if rank == 0:
+        full_s, full_c = O.all_pairs(p)
+        q.put((np.array_equal(s.numpy(), full_s), np.array_equal(c.numpy().astype(np.uint64), full_c)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_site_shards_add_up_exactly():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_site_worker, args=(r, 2, port, 30, 501, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    ok_s, ok_c = q.get(timeout=10)
+    assert ok_s and ok_c
+
+
 def test_shard_owner_covers_every_pair_once():
     os.environ.setdefault("NGD_NO_TORCH", "1")
     from ngsdist_amd.dist import shard_of_pairs

@@ -334,3 +334,62 @@ def test_all_zero_site_vectors_count_and_contribute_nothing():
             assert np.array_equal(np.isnan(s), np.isnan(so))
             ok = ~np.isnan(so)
             assert rel_err(s[ok], so[ok]) < RTOL
+
+
+# ---- site sharding: engines hold contiguous ranges of sites, (sum, cnt) are added -----------------------
+@pytest.mark.parametrize("kernel", ["mfma", "em_fast", "stream"])
+def test_site_shards_add_up(kernel):
+    n_ind, n_sites, B, world = 70, 1200, 20, 3
+    indep = kernel != "em_fast"
+    p = O.synth_indmajor(23, n_ind, n_sites, miss_frac=0.1)
+    cuts = [0, 400, 820, 1200]  # whole blocks of 20 sites per shard
+    engines = []
+    for r in range(world):
+        e = N().Engine(n_ind, cuts[r + 1] - cuts[r], pairwise_del=True, indep_geno=indep, kernel=kernel)
+        e.upload_ind_major(p[:, cuts[r]:cuts[r + 1]]).commit()
+        engines.append(e)
+    try:
+        # full data set
+        s = sum(e.run()[0] for e in engines)
+        c = sum(e.run()[1] for e in engines)
+        so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, n_threads=8)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        # a bootstrap replicate: the global block map becomes per-shard multiplicities
+        rng = N().Taus(77)
+        for rep in range(2):
+            bm = rng.block_map(n_sites // B)
+            mult = np.bincount(bm.astype(np.int64), minlength=n_sites // B).astype(np.uint32)
+            tot_s = np.zeros(N().n_pairs(n_ind))
+            tot_c = np.zeros(N().n_pairs(n_ind), dtype=np.uint64)
+            for r, e in enumerate(engines):
+                ms = mult[cuts[r] // B:cuts[r + 1] // B]
+                sr, cr = e.run_mult(ms, B)
+                tot_s += sr
+                tot_c += cr
+            so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, site_src=O.boot_site_src(bm, B), n_threads=8)
+            assert np.array_equal(tot_c, co) and rel_err(tot_s, so) < RTOL
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_site_shards_bit_exact_for_called_genotypes_and_synth_ranges():
+    n_ind, n_sites = 40, 3000
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    so, co = O.all_pairs(p, n_threads=8)
+    tot = np.zeros_like(so)
+    for lo, hi in ((0, 1111), (1111, 2000), (2000, 3000)):
+        with N().Engine(n_ind, hi - lo, kernel="mfma") as e:
+            tot += e.upload_ind_major(p[:, lo:hi]).commit().run()[0]
+    assert np.array_equal(tot, so)  # dyadic terms: any split of the site axis is exact
+    # the synthetic generator addressed by range reproduces the whole set
+    ps = O.synth_indmajor(9, n_ind, n_sites)
+    so, co = O.all_pairs(ps, n_threads=8)
+    tot = np.zeros_like(so)
+    for lo, hi in ((0, 1000), (1000, 3000)):
+        with N().Engine(n_ind, hi - lo, kernel="mfma") as e:
+            tot += e.synth_fill(9, 0.0, site0=lo).run()[0]
+    assert rel_err(tot, so) < RTOL
