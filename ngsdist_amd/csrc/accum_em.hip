@@ -83,28 +83,40 @@ __device__ __forceinline__ double site_faithful(const double *g1, const double *
 __device__ __forceinline__ double site_fast(const double *g1, const double *g2, const ngd_score &sc,
                                             double acc, double w) {
   const double E = 0x1.0041919b7ee34p+0;  // exp(0.001), the tolerance of ngsDist.cpp:349
-  double u1[3] = {g1[0], g1[1], g1[2]}, u2[3] = {g2[0], g2[1], g2[2]};
-  double Sm = 9.0;                                                     // S_0 (uniform start, 9 cells)
-  double Sc = ((u1[0] + u1[1]) + u1[2]) * ((u2[0] + u2[1]) + u2[2]);   // S_1
-  for (int t = 1;; t++) {
-    double n1[3], n2[3];
+  double u1[3] = {g1[0], g1[1], g1[2]}, u2[3] = {g2[0], g2[1], g2[2]};  // g^t      (t odd)
+  double n1[3], n2[3];                                                  // g^(t+1)
+  double Sm = 9.0;                                                     // S_{t-1}; S_0 = 9 (uniform start)
+  double Sc = ((u1[0] + u1[1]) + u1[2]) * ((u2[0] + u2[1]) + u2[2]);   // S_t;     S_1
+  double Sn = 0;                                                       // S_{t+1}
+  // |lik_t - lik_{t-1}| < tole  <=>  S_{t+1} S_{t-1} < e^tole S_t^2   (lik is non-decreasing).
+  // Two steps per trip, the powers alternating between u and n, so that nothing is copied per step; a
+  // lane that stops is masked off and keeps its registers, and `even` says which of the two holds g^T.
+  int even = 0;
+  for (int t = 1;; t += 2) {
 #pragma unroll
     for (int x = 0; x < 3; x++) { n1[x] = u1[x] * g1[x]; n2[x] = u2[x] * g2[x]; }
-    const double Sn = ((n1[0] + n1[1]) + n1[2]) * ((n2[0] + n2[1]) + n2[2]);  // S_{t+1}
-    // |lik_t - lik_{t-1}| < tole  <=>  S_{t+1} S_{t-1} < e^tole S_t^2   (lik is non-decreasing)
-    const bool stop = (Sn * Sm < E * (Sc * Sc)) || t == MAX_ITER;
-    if (stop) break;
+    Sn = ((n1[0] + n1[1]) + n1[2]) * ((n2[0] + n2[1]) + n2[2]);
+    if (Sn * Sm < E * (Sc * Sc)) break;  // T = t (odd, so never MAX_ITER): g^T = u, S_T = Sc
 #pragma unroll
-    for (int x = 0; x < 3; x++) { u1[x] = n1[x]; u2[x] = n2[x]; }
-    Sm = Sc; Sc = Sn;
+    for (int x = 0; x < 3; x++) { u1[x] = n1[x] * g1[x]; u2[x] = n2[x] * g2[x]; }
+    const double Su = ((u1[0] + u1[1]) + u1[2]) * ((u2[0] + u2[1]) + u2[2]);  // S_{t+2}
+    if (Su * Sc < E * (Sn * Sn) || t + 1 == MAX_ITER) { even = 1; break; }  // T = t+1: g^T = n, S_T = Sn
+    Sm = Sn;
+    Sc = Su;
   }
-  double c = 0;
+  // Both candidates are scored and the RESULT is selected: selecting the inputs (g^T = even ? n : u)
+  // makes the compiler copy six registers at every loop exit, i.e. in every trip.
+  auto scored = [&](const double *a, const double *b, double S) {
+    double c = 0;
 #pragma unroll
-  for (int x = 0; x < 3; x++) {
-    const double q = (sc.v[3 * x] * u2[0] + sc.v[3 * x + 1] * u2[1]) + sc.v[3 * x + 2] * u2[2];
-    c += u1[x] * q;
-  }
-  return acc + (c / Sc) * w;
+    for (int x = 0; x < 3; x++) {
+      const double q = (sc.v[3 * x] * b[0] + sc.v[3 * x + 1] * b[1]) + sc.v[3 * x + 2] * b[2];
+      c += a[x] * q;
+    }
+    return c / S;
+  };
+  const double cu = scored(u1, u2, Sc), cn = scored(n1, n2, Sn);
+  return acc + (even ? cn : cu) * w;
 }
 
 template <bool FAST, bool WEIGHTED, bool PDEL>
