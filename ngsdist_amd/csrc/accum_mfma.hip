@@ -52,7 +52,7 @@ __device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const 
 // panel of a slice is a few tens of KB.
 template <bool WEIGHTED, int DEPTH, int WPS, bool EXACT>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
-    const double *__restrict__ PA, const double *__restrict__ QB, const uint32_t *__restrict__ ws,
+    const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
@@ -86,9 +86,10 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 
   constexpr int RING = DEPTH;
   double a[RING][WM], bq[RING][WN];
-  uint32_t wq[RING];
+  double wq[RING];  // bootstrap multiplicity of this lane's k (wk[4 kg + lane/16])
 #pragma unroll
   for (int d = 0; d < RING; d++) wq[d] = 0;
+  uint32_t lane_wk = (lane >> 4) * 8;  // (not const: a nested generic lambda must capture it)
 
   // The operand pipeline is issued by hand.  hipcc's waitcnt pass puts a full
   // `s_waitcnt vmcnt(0)` at the head of any loop whose loads are consumed one
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
         : "=&v"(bq[d][0]), "=&v"(bq[d][1]), "=&v"(bq[d][2]), "=&v"(bq[d][3])
         : "v"(lane_off), "s"(xb));
     if (WEIGHTED) {
-      const uint32_t *xw = ws + (kg * 4 + (uint64_t)(lane >> 4)) / 3;
-      asm volatile("global_load_dword %0, %1, off" : "=&v"(wq[d]) : "v"(xw));
+      const double *xw = wk + kg * 4;
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(wq[d]) : "v"(lane_wk), "s"(xw));
     }
   };
   auto arrive = [&](int d) {  // wait until fetch #d (the oldest outstanding) has landed
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
         arrive(d);
         if (DEPTH == 1 || kg + d < kg1) {  // a slice need not be a whole number of ring trips
           if (WEIGHTED) {  // bootstrap multiplicity of the site (ngsDist.cpp:426-434)
-            const double w = (double)wq[d];
+            const double w = wq[d];
 #pragma unroll
             for (int m = 0; m < WM; m++) a[d][m] *= w;
           }
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value, D = decltype(depth_c)::value;
     constexpr bool TRI = decltype(tri_c)::value;
     constexpr int LOADS = PM + PN + (WEIGHTED ? 1 : 0);
+    const uint32_t lwk = lane_wk;  // named here so that the nested lambda captures it
     auto fetch_x = [&](int d, uint64_t kg) {
       const double *xa = pa + kg * kstride;
       const double *xb = pb + kg * kstride;
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
       if (PN > 2) load_frag<1024>(bq[d][2], lane_off, xb);
       if (PN > 3) load_frag<1536>(bq[d][3], lane_off, xb);
       if (WEIGHTED) {
-        const uint32_t *xw = ws + (kg * 4 + (uint64_t)(lane >> 4)) / 3;
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(wq[d]) : "v"(xw));
+        const double *xw = wk + kg * 4;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(wq[d]) : "v"(lwk), "s"(xw));
       }
     };
     auto arrive_x = [&](int d) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
         arrive_x(d);
         if (D == 1 || kg + d < kg1) {
           if (WEIGHTED) {
-            const double w = (double)wq[d];
+            const double w = wq[d];
 #pragma unroll
             for (int m = 0; m < PM; m++) a[d][m] *= w;
           }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 }  // namespace
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
+                           const double *d_ws /* wk */, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
                            uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
   if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)

@@ -42,6 +42,7 @@ struct ngd_engine {
   unsigned long long *mask = nullptr, *planes = nullptr;
   // bootstrap
   uint32_t *d_mult = nullptr, *d_ws = nullptr;
+  double *d_wk = nullptr;  // multiplicity per contraction index k, as a double (MFMA kernel)
   uint64_t cap_blocks = 0;
   // shard
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
@@ -109,7 +110,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws,
+  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk,
                   e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->d_wslice};
   for (void *p : ptrs)
@@ -304,6 +305,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     TRY(dev_alloc(e, &e->planes, 32ull * g.n_words, true));
   }
   TRY(dev_alloc(e, &e->d_ws, g.n_sites_pad + 4 * NGD_KG_TAIL, true));
+  if (kernel == NGD_KERNEL_MFMA) TRY(dev_alloc(e, &e->d_wk, 4 * (g.n_kg + NGD_KG_TAIL), true));
   TRY(dev_alloc(e, &e->d_sum, n_pairs, true));
   TRY(dev_alloc(e, &e->d_cnt, n_pairs, true));
 
@@ -512,7 +514,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, const uint32_t *mu
       e->cap_blocks = n_blocks;
     }
     HIPCHK(hipMemcpyAsync(e->d_mult, mult.data(), n_blocks * 4, hipMemcpyHostToDevice, e->st));
-    ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws);
+    ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws, e->d_wk);
     HIPCHK(hipStreamSynchronize(e->st));  // `mult` is pageable host memory
     ws = e->d_ws;
   }
@@ -527,8 +529,8 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, const uint32_t *mu
         if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
           ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
         else
-          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
-                                kg_lim, slab);
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, e->d_jobs, e->n_wg, e->exact_shapes,
+                                n_ks, per_slice, kg_lim, slab);
         break;
       default:
         ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,

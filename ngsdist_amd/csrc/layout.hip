@@ -130,11 +130,20 @@ __global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, uint64_t si
   emit(g, sc, pairwise_del, s, i, p0, p1, p2, PA, QB, PI, mask);
 }
 
+// per-site multiplicity ws[s] (EM / streaming kernels, count planes) and, for the MFMA kernel, the
+// same thing per contraction index k = 3 s + g as a double, wk[k], so that its operand pipeline fetches the
+// weight of a k-group like any other operand (no integer division, no conversion in the hot loop)
 __global__ void k_expand(const uint32_t *__restrict__ mult, uint64_t n_eff, uint64_t block_size,
-                         uint64_t n_sites, uint32_t *ws) {
+                         uint64_t n_sites, uint32_t *ws, double *wk) {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_sites) return;
-  ws[s] = s < n_eff ? mult[s / block_size] : 0u;
+  const uint32_t m = s < n_eff ? mult[s / block_size] : 0u;
+  ws[s] = m;
+  if (wk) {
+    wk[3 * s] = (double)m;
+    wk[3 * s + 1] = (double)m;
+    wk[3 * s + 2] = (double)m;
+  }
 }
 
 // bit-planes of the per-site multiplicity, for weighted valid-site counts
@@ -182,9 +191,9 @@ void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double m
 }
 
 void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
-                        const uint32_t *d_mult, uint32_t *d_ws) {
+                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk) {
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, d_mult,
-                     n_blocks * block_size, block_size, n_sites, d_ws);
+                     n_blocks * block_size, block_size, n_sites, d_ws, d_wk);
 }
 
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,

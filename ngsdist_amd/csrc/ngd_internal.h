@@ -78,7 +78,7 @@ void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double m
                       const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                       unsigned long long *mask);
 void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
-                        const uint32_t *d_mult, uint32_t *d_ws);
+                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 
@@ -89,7 +89,7 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
 
 // accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const uint32_t *d_ws, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
+                           const double *d_wk, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
                            uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
 
 // accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
