@@ -165,8 +165,26 @@ int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_
 int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
                         uint64_t block_size, void *d_sum, void *d_cnt);
 
-/* Bootstrap replicates re-use per-block partial sums computed on the first
- * ngd_run() that carries a block map (valid for that block size / block count;
+/* n_rep bootstrap replicates in ONE call: n_rep turns of the replicate loop ngsDist.cpp:217-289 (each
+ * = rnd_map_data :416-437 + the fan-out/wait :244-269).  block_maps is [n_rep][n_blocks], replicate r's
+ * map being what the r-th rnd_map_data() call would draw (the taus stream is consumed by nothing else,
+ * so a host may draw all maps up front: ngd_boot_block_map n_rep times); mult is [n_rep][n_blocks]
+ * (site sharding, as ngd_run_mult).  Outputs are [n_rep][n_pairs].  The engine computes per-block partial
+ * (sum, cnt) once and forms up to 32 replicates per pass over them, so a batch costs little more than
+ * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run().
+ * When the partials do not apply (streaming kernel, MFMA kernel with block_size % 4 != 0, not enough
+ * device memory) this is n_rep weighted accumulation passes. */
+int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                  uint64_t block_size, double *sum, uint64_t *cnt);
+int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                         uint64_t block_size, void *d_sum, void *d_cnt);
+int ngd_run_mult_batch(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks,
+                       uint64_t block_size, double *sum, uint64_t *cnt);
+int ngd_run_mult_batch_device(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks,
+                              uint64_t block_size, void *d_sum, void *d_cnt);
+
+/* Bootstrap replicates re-use per-block partial (sum, cnt) computed on the first
+ * run that carries a block map (valid for that block size / block count;
  * recomputed automatically when either changes).  This forgets them, so that a
  * benchmark can charge the partial-sum pass to every timed step. */
 int ngd_drop_caches(ngd_engine *e);

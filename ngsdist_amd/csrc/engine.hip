@@ -60,9 +60,20 @@ struct ngd_engine {
   double *d_sum = nullptr;
   unsigned long long *d_cnt = nullptr;
   // bootstrap by per-block partial sums (valid while boot_B != 0)
-  double *slab_boot = nullptr, *d_wslice = nullptr;
+  double *slab_boot = nullptr;
   uint64_t boot_B = 0, boot_blocks = 0, boot_per_slice = 0, slab_boot_elems = 0;
   uint32_t boot_nks = 0, boot_sub = 0;
+  uint32_t *cnt_boot = nullptr;  // per-block valid-site counts [n_blocks][n_pad][n_pad] (--pairwise_del)
+  uint64_t cnt_B = 0, cnt_blocks = 0, cnt_boot_elems = 0;
+  // per-call bootstrap weights (slice-major doubles / block-major uint32) and per-replicate site totals
+  double *d_W = nullptr;
+  uint32_t *d_M = nullptr;
+  unsigned long long *d_drawn = nullptr;
+  uint64_t cap_W = 0, cap_M = 0, cap_drawn = 0;
+  // batch results for the host-pointer entry points
+  double *d_bsum = nullptr;
+  unsigned long long *d_bcnt = nullptr;
+  uint64_t cap_batch = 0;
   double *staging = nullptr;
   uint64_t staging_sites = 0;
   // raw-input pipeline: two pinned host buffers + two device buffers, alternating
@@ -83,6 +94,18 @@ static int dev_alloc(ngd_engine *e, T **p, uint64_t count, bool zero) {
   HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
   e->dev_bytes += count * sizeof(T);
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), e->st));
+  return NGD_OK;
+}
+
+// grow-only device scratch
+template <typename T>
+static int ensure_cap(ngd_engine *e, T **p, uint64_t *cap, uint64_t need) {
+  if (need <= *cap) return NGD_OK;
+  if (*p) { HIPCHK(hipFree(*p)); e->dev_bytes -= *cap * sizeof(T); }
+  *p = nullptr; *cap = 0;
+  int rc = dev_alloc(e, p, need, false);
+  if (rc) return rc;
+  *cap = need;
   return NGD_OK;
 }
 
@@ -112,7 +135,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk,
                   e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->d_wslice};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -469,43 +492,49 @@ int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_
 
 int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) { return ngd_synth_fill_range(e, seed, miss_frac, 0); }
 
-// block_map != NULL: multiplicities are counted from it; else mult_in != NULL: they are given; else rep 0.
-static int run_impl(ngd_engine *e, const uint64_t *block_map, const uint32_t *mult_in, uint64_t n_blocks,
-                    uint64_t block_size, double *d_sum, unsigned long long *d_cnt) {
-  if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
-  if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
-  HIPCHK(hipSetDevice(e->device));
+static void launch_accumulate(ngd_engine *e, const uint32_t *w, uint64_t sites_eff, uint32_t n_ks, uint64_t per_slice,
+                              uint64_t kg_lim, double *slab) {
+  const ngd_geom &g = e->g;
+  switch (e->kernel) {
+    case NGD_KERNEL_MFMA:
+      if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
+        ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
+      else
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, e->d_jobs, e->n_wg, e->exact_shapes,
+                              n_ks, per_slice, kg_lim, slab);
+      break;
+    default:
+      ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
+                          e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
+  }
+}
+
+static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool add) {
+  float ms[4] = {0, 0, 0, 0};
+  hipEventElapsedTime(&ms[0], e->ev[0], e->ev[4]);
+  hipEventElapsedTime(&ms[1], e->ev[1], e->ev[2]);
+  hipEventElapsedTime(&ms[2], e->ev[2], e->ev[3]);
+  hipEventElapsedTime(&ms[3], e->ev[3], e->ev[4]);
+  ngd_timing &t = e->timing;
+  if (!add) t = ngd_timing{};
+  t.ms_total += ms[0]; t.ms_accum += ms[1]; t.ms_reduce += ms[2]; t.ms_count += ms[3];
+  t.pair_sites += e->n_owned_pairs * n_eff;
+  t.launches += launches;
+}
+
+// One accumulation pass over the resident data set: the full data set (mult == NULL) or one bootstrap
+// replicate given as block multiplicities (applied inside the accumulation kernel).
+static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uint64_t n_blocks, uint64_t block_size,
+                     uint64_t n_drawn, double *d_sum, unsigned long long *d_cnt, bool add_timing) {
   const ngd_geom &g = e->g;
   const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
   uint64_t n_eff = g.n_sites;
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
-  const bool boot = block_map || mult_in;
-
-  std::vector<uint32_t> mult;
-  uint64_t n_drawn = 0;  // sites visited, with multiplicity = gen_dist's cnt without --pairwise_del
   HIPCHK(hipEventRecord(e->ev[0], e->st));
-  if (boot) {
-    if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
-    if (n_blocks > g.n_sites / block_size)
-      return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
+  if (mult) {
     n_eff = n_blocks * block_size;
-    uint32_t mx = 0;
-    if (block_map) {
-      mult.assign(n_blocks, 0);
-      for (uint64_t b = 0; b < n_blocks; b++) {
-        if (block_map[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
-        mx = std::max(mx, ++mult[block_map[b]]);
-      }
-      n_drawn = n_eff;
-    } else {
-      mult.assign(mult_in, mult_in + n_blocks);
-      for (uint64_t b = 0; b < n_blocks; b++) {
-        mx = std::max(mx, mult[b]);
-        n_drawn += (uint64_t)mult[b] * block_size;
-      }
-    }
-    while (n_planes < 32 && (mx >> n_planes)) n_planes++;
+    while (n_planes < 32 && (mult_max >> n_planes)) n_planes++;
     if (n_blocks > e->cap_blocks) {
       if (e->d_mult) { hipFree(e->d_mult); e->dev_bytes -= e->cap_blocks * 4; }
       e->d_mult = nullptr; e->cap_blocks = 0;
@@ -513,163 +542,290 @@ static int run_impl(ngd_engine *e, const uint64_t *block_map, const uint32_t *mu
       if (rc) return rc;
       e->cap_blocks = n_blocks;
     }
-    HIPCHK(hipMemcpyAsync(e->d_mult, mult.data(), n_blocks * 4, hipMemcpyHostToDevice, e->st));
+    HIPCHK(hipMemcpyAsync(e->d_mult, mult, n_blocks * 4, hipMemcpyHostToDevice, e->st));
     ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws, e->d_wk);
     HIPCHK(hipStreamSynchronize(e->st));  // `mult` is pageable host memory
     ws = e->d_ws;
   }
-
   HIPCHK(hipMemsetAsync(d_sum, 0, n_pairs * sizeof(double), e->st));
   HIPCHK(hipMemsetAsync(d_cnt, 0, n_pairs * sizeof(unsigned long long), e->st));
-
-  auto accumulate = [&](const uint32_t *w, uint64_t sites_eff, uint32_t n_ks, uint64_t per_slice, uint64_t kg_lim,
-                        double *slab) {
-    switch (e->kernel) {
-      case NGD_KERNEL_MFMA:
-        if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
-          ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
-        else
-          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, e->d_jobs, e->n_wg, e->exact_shapes,
-                                n_ks, per_slice, kg_lim, slab);
-        break;
-      default:
-        ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
-                            e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
-    }
-  };
-
-  // Bootstrap by per-block partial sums: every site's contribution is independent of
-  // the replicate, so sum_rep = SUM_b multiplicity_rep[b] * S_b with S_b the block's partial sum.
-  // One extra accumulation pass fills S_b; each replicate is then a weighted slab reduction.
-  // MFMA slices are whole k-groups of 4, so blocks must be multiples of 4 sites there.
-  bool partials = false;
-  uint32_t launches = 1;
-  if (boot && e->kernel != NGD_KERNEL_STREAM && env_u64("NGD_BOOT_PARTIALS", 1)) {
-    const bool mfma = e->kernel == NGD_KERNEL_MFMA;
-    if (!mfma || block_size % 4 == 0) {
-      // split large blocks so that there are enough workgroups; slices of one block share its weight
-      const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
-      const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1)) : e->n_tiles16;
-      uint64_t sub = 1;
-      const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
-      while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)
-        sub *= 2;
-      uint64_t nks = n_blocks * sub;
-      if (mfma) nks = (nks + 7) / 8 * 8;  // the XCD deal of accum_mfma.hip
-      const uint64_t elems = nks * (uint64_t)g.n_pad * g.n_pad;
-      size_t free_b = 0, total_b = 0;
-      HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)(total_b / 4));
-      const bool cached = e->boot_B == block_size && e->boot_blocks == n_blocks;
-      if (cached || (elems * 8 <= budget && (elems <= e->slab_boot_elems || elems * 8 + (1ull << 30) <= free_b))) {
-        partials = true;
-        if (!cached) {
-          e->boot_B = 0;
-          if (elems > e->slab_boot_elems) {
-            if (e->slab_boot) { HIPCHK(hipFree(e->slab_boot)); e->dev_bytes -= e->slab_boot_elems * 8; }
-            if (e->d_wslice) { HIPCHK(hipFree(e->d_wslice)); e->dev_bytes -= e->slab_boot_elems / ((uint64_t)g.n_pad * g.n_pad) * 8; }
-            e->slab_boot = nullptr; e->d_wslice = nullptr; e->slab_boot_elems = 0;
-            int rc = dev_alloc(e, &e->slab_boot, elems, false);
-            if (rc) return rc;
-            rc = dev_alloc(e, &e->d_wslice, nks, false);
-            if (rc) return rc;
-            e->slab_boot_elems = elems;
-          }
-          e->boot_nks = (uint32_t)nks;
-          e->boot_sub = (uint32_t)sub;
-          e->boot_per_slice = unit / sub;
-          HIPCHK(hipEventRecord(e->ev[1], e->st));
-          accumulate(nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
-          HIPCHK(hipGetLastError());
-          HIPCHK(hipEventRecord(e->ev[2], e->st));
-          e->boot_B = block_size;
-          e->boot_blocks = n_blocks;
-        } else {
-          HIPCHK(hipEventRecord(e->ev[1], e->st));
-          HIPCHK(hipEventRecord(e->ev[2], e->st));
-          launches = 0;
-        }
-        std::vector<double> wslice(e->boot_nks, 0.0);
-        for (uint64_t b = 0; b < n_blocks; b++)
-          for (uint32_t q = 0; q < e->boot_sub; q++) wslice[b * e->boot_sub + q] = (double)mult[b];
-        HIPCHK(hipMemcpyAsync(e->d_wslice, wslice.data(), wslice.size() * 8, hipMemcpyHostToDevice, e->st));
-        ngd_launch_reduce_w(e->st, g, e->slab_boot, e->boot_nks, e->d_wslice, e->d_tiles, e->n_tiles, d_sum);
-        HIPCHK(hipStreamSynchronize(e->st));  // wslice is a host temporary
-      }
-    }
-  }
-
-  if (!partials) {
-    HIPCHK(hipEventRecord(e->ev[1], e->st));
-    if (e->kernel == NGD_KERNEL_STREAM)
-      ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
-                              e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
-    else
-      accumulate(ws, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev[2], e->st));
-    if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
-  }
+  HIPCHK(hipEventRecord(e->ev[1], e->st));
+  if (e->kernel == NGD_KERNEL_STREAM)
+    ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
+                            e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
+  else
+    launch_accumulate(e, ws, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[2], e->st));
+  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
     ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles16, e->n_tiles16, d_cnt);
   } else {
-    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, boot ? n_drawn : n_eff, d_cnt);
+    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, mult ? n_drawn : n_eff, nullptr, 1, d_cnt);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));
+  read_timing(e, n_eff, 1, add_timing);
+  return NGD_OK;
+}
 
-  float ms = 0;
-  ngd_timing &t = e->timing;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[4])); t.ms_total = ms;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); t.ms_accum = ms;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); t.ms_reduce = ms;
-  HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); t.ms_count = ms;
-  t.pair_sites = e->n_owned_pairs * n_eff;
-  t.launches = launches;
+// Bootstrap by per-block partials: every site's contribution is independent of the
+// replicate, so sum_rep = SUM_b multiplicity_rep[b] * S_b with S_b the block's partial sum (and the same
+// for the valid-site counts).  One accumulation pass fills S_b; replicates are then weighted reductions of
+// the partials, up to 32 per pass over them.  MFMA slices are whole k-groups of 4 contraction indices, so
+// blocks must be multiples of 4 sites there.  *feasible = false: the caller falls back to pass_impl().
+static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]*/, const unsigned long long *drawn,
+                         uint32_t n_rep, uint64_t n_blocks, uint64_t block_size, double *d_sum,
+                         unsigned long long *d_cnt, bool *feasible) {
+  const ngd_geom &g = e->g;
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
+  const uint64_t n_eff = n_blocks * block_size;
+  const uint64_t plane = (uint64_t)g.n_pad * g.n_pad;
+  const bool mfma = e->kernel == NGD_KERNEL_MFMA;
+  const bool pdel = e->cfg.pairwise_del != 0;
+  *feasible = false;
+  if (e->kernel == NGD_KERNEL_STREAM || !env_u64("NGD_BOOT_PARTIALS", 1)) return NGD_OK;
+  if (mfma && (block_size % 4 != 0 || env_u64("NGD_MFMA_VARIANT", 0) >= 2)) return NGD_OK;
+  if (n_blocks >= (1ull << 31)) return NGD_OK;
+  // split large blocks so that there are enough workgroups; slices of one block share its weight
+  const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
+  const bool cached = e->boot_B == block_size && e->boot_blocks == n_blocks;
+  uint64_t sub = 1, nks = 0;
+  if (cached) {
+    sub = e->boot_sub;
+    nks = e->boot_nks;
+  } else {
+    const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1)) : e->n_tiles16;
+    const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
+    while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)
+      sub *= 2;
+    nks = n_blocks * sub;
+    if (mfma) nks = (nks + 7) / 8 * 8;  // the XCD deal of accum_mfma.hip
+  }
+  if (nks >= (1ull << 31)) return NGD_OK;
+  const uint64_t elems = nks * plane, c_elems = pdel ? n_blocks * plane : 0;
+  const bool c_cached = !pdel || (e->cnt_B == block_size && e->cnt_blocks == n_blocks);
+  if (!cached || !c_cached) {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)(total_b / 4));
+    const uint64_t need = elems * 8 + c_elems * 4;
+    const uint64_t have = e->slab_boot_elems * 8 + e->cnt_boot_elems * 4;
+    if (need > budget) return NGD_OK;
+    if ((elems > e->slab_boot_elems || c_elems > e->cnt_boot_elems) && need + (1ull << 30) > free_b + have)
+      return NGD_OK;
+  }
+  *feasible = true;
+
+  HIPCHK(hipEventRecord(e->ev[0], e->st));
+  uint32_t launches = 0;
+  HIPCHK(hipEventRecord(e->ev[1], e->st));
+  if (!cached) {
+    e->boot_B = 0;
+    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, elems);
+    if (rc) return rc;
+    e->boot_nks = (uint32_t)nks;
+    e->boot_sub = (uint32_t)sub;
+    e->boot_per_slice = unit / sub;
+    launch_accumulate(e, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
+    HIPCHK(hipGetLastError());
+    e->boot_B = block_size;
+    e->boot_blocks = n_blocks;
+    launches = 1;
+  }
+  HIPCHK(hipEventRecord(e->ev[2], e->st));
+
+  // W[slice][r]: slice-major, so that the replicates of one pass read their weights of a slice together
+  const uint32_t stride = (n_rep + ngd_reduce_chunk(n_rep) - 1) / ngd_reduce_chunk(n_rep) * ngd_reduce_chunk(n_rep);
+  const uint64_t n_slices = n_blocks * sub;  // the slab's padding slices (MFMA deal) are never read
+  std::vector<double> W(n_slices * stride, 0.0);
+  for (uint32_t r = 0; r < n_rep; r++)
+    for (uint64_t b = 0; b < n_blocks; b++) {
+      const double m = (double)mult[(uint64_t)r * n_blocks + b];
+      if (m != 0.0)
+        for (uint64_t q = 0; q < sub; q++) W[(b * sub + q) * stride + r] = m;
+    }
+  int rc = ensure_cap(e, &e->d_W, &e->cap_W, W.size());
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(e->d_W, W.data(), W.size() * 8, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipMemsetAsync(d_sum, 0, (uint64_t)n_rep * n_pairs * sizeof(double), e->st));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_rep * n_pairs * sizeof(unsigned long long), e->st));
+  ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[3], e->st));
+
+  std::vector<uint32_t> M;
+  if (pdel) {
+    if (!c_cached) {
+      e->cnt_B = 0;
+      rc = ensure_cap(e, &e->cnt_boot, &e->cnt_boot_elems, c_elems);
+      if (rc) return rc;
+      ngd_launch_count_blocks(e->st, g, e->mask, block_size, (uint32_t)n_blocks, e->d_tiles16, e->n_tiles16, e->cnt_boot);
+      HIPCHK(hipGetLastError());
+      e->cnt_B = block_size;
+      e->cnt_blocks = n_blocks;
+    }
+    M.assign(n_blocks * stride, 0u);
+    for (uint32_t r = 0; r < n_rep; r++)
+      for (uint64_t b = 0; b < n_blocks; b++) M[b * stride + r] = mult[(uint64_t)r * n_blocks + b];
+    rc = ensure_cap(e, &e->d_M, &e->cap_M, M.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_M, M.data(), M.size() * 4, hipMemcpyHostToDevice, e->st));
+    ngd_launch_reduce_c(e->st, g, e->cnt_boot, (uint32_t)n_blocks, e->d_M, stride, n_rep, e->d_tiles, e->n_tiles, d_cnt);
+  } else {
+    rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_rep);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_drawn, drawn, (uint64_t)n_rep * 8, hipMemcpyHostToDevice, e->st));
+    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, 0, e->d_drawn, n_rep, d_cnt);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[4], e->st));
+  HIPCHK(hipStreamSynchronize(e->st));  // W, M, drawn are host temporaries
+  read_timing(e, n_eff, launches, false);
+  e->timing.pair_sites = e->n_owned_pairs * n_eff * n_rep;
+  return NGD_OK;
+}
+
+// n_rep == 0: the full data set (rep 0).  Else n_rep bootstrap replicates, given as block maps
+// (multiplicities are counted from them) or directly as multiplicities; outputs are [n_rep][n_pairs].
+static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *mult_in, uint32_t n_rep,
+                    uint64_t n_blocks, uint64_t block_size, double *d_sum, unsigned long long *d_cnt) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
+  if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
+  HIPCHK(hipSetDevice(e->device));
+  const ngd_geom &g = e->g;
+  if (!n_rep) return pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
+
+  if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
+  if (n_blocks > g.n_sites / block_size) return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
+  const uint64_t n_eff = n_blocks * block_size;
+  std::vector<uint32_t> counted;
+  std::vector<unsigned long long> drawn(n_rep, 0);  // sites visited, with multiplicity = gen_dist's cnt
+  std::vector<uint32_t> mult_max(n_rep, 0);
+  const uint32_t *mult = mult_in;
+  if (block_maps) {
+    counted.assign((uint64_t)n_rep * n_blocks, 0);
+    for (uint32_t r = 0; r < n_rep; r++) {
+      uint32_t *m = &counted[(uint64_t)r * n_blocks];
+      const uint64_t *bm = block_maps + (uint64_t)r * n_blocks;
+      for (uint64_t b = 0; b < n_blocks; b++) {
+        if (bm[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
+        mult_max[r] = std::max(mult_max[r], ++m[bm[b]]);
+      }
+      drawn[r] = n_eff;
+    }
+    mult = counted.data();
+  } else {
+    for (uint32_t r = 0; r < n_rep; r++)
+      for (uint64_t b = 0; b < n_blocks; b++) {
+        const uint32_t m = mult[(uint64_t)r * n_blocks + b];
+        mult_max[r] = std::max(mult_max[r], m);
+        drawn[r] += (unsigned long long)m * block_size;
+      }
+  }
+  bool feasible = false;
+  int rc = partials_impl(e, mult, drawn.data(), n_rep, n_blocks, block_size, d_sum, d_cnt, &feasible);
+  if (rc || feasible) return rc;
+  for (uint32_t r = 0; r < n_rep; r++) {  // one weighted accumulation pass per replicate
+    rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[r], n_blocks, block_size, drawn[r],
+                   d_sum + (uint64_t)r * n_pairs, d_cnt + (uint64_t)r * n_pairs, r > 0);
+    if (rc) return rc;
+  }
+  return NGD_OK;
+}
+
+static int copy_out(ngd_engine *e, uint32_t n_mat, const double *d_sum, const unsigned long long *d_cnt, double *sum,
+                    uint64_t *cnt) {
+  const uint64_t n = (uint64_t)n_mat * ngd_n_pairs(e->g.n_ind);
+  if (sum) HIPCHK(hipMemcpy(sum, d_sum, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (cnt) HIPCHK(hipMemcpy(cnt, d_cnt, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return NGD_OK;
+}
+
+static int batch_buffers(ngd_engine *e, uint32_t n_rep) {
+  HIPCHK(hipSetDevice(e->device));
+  const uint64_t need = (uint64_t)n_rep * ngd_n_pairs(e->g.n_ind);
+  if (need <= e->cap_batch) return NGD_OK;
+  uint64_t cap_s = e->cap_batch, cap_c = e->cap_batch;
+  int rc = ensure_cap(e, &e->d_bsum, &cap_s, need);
+  if (rc) { e->cap_batch = 0; return rc; }
+  rc = ensure_cap(e, &e->d_bcnt, &cap_c, need);
+  if (rc) { e->cap_batch = 0; return rc; }
+  e->cap_batch = need;
   return NGD_OK;
 }
 
 int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
                    void *d_sum, void *d_cnt) {
   if (!d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_device: null output");
-  return run_impl(e, block_map, nullptr, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, block_map, nullptr, block_map ? 1 : 0, n_blocks, block_size, (double *)d_sum,
+                  (unsigned long long *)d_cnt);
 }
 
 int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, void *d_sum,
                         void *d_cnt) {
   if (!d_sum || !d_cnt || !mult) return fail(NGD_E_INVALID, "ngd_run_mult_device: null argument");
-  return run_impl(e, nullptr, mult, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, nullptr, mult, 1, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
 }
 
 int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, double *sum,
                  uint64_t *cnt) {
   if (!e || !mult) return fail(NGD_E_INVALID, "ngd_run_mult: null argument");
-  int rc = run_impl(e, nullptr, mult, n_blocks, block_size, e->d_sum, e->d_cnt);
+  int rc = run_impl(e, nullptr, mult, 1, n_blocks, block_size, e->d_sum, e->d_cnt);
   if (rc) return rc;
-  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
-  if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));
-  if (cnt) HIPCHK(hipMemcpy(cnt, e->d_cnt, n_pairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  return NGD_OK;
+  return copy_out(e, 1, e->d_sum, e->d_cnt, sum, cnt);
 }
 
 int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size, double *sum,
             uint64_t *cnt) {
   if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
-  int rc = run_impl(e, block_map, nullptr, n_blocks, block_size, e->d_sum, e->d_cnt);
+  int rc = run_impl(e, block_map, nullptr, block_map ? 1 : 0, n_blocks, block_size, e->d_sum, e->d_cnt);
   if (rc) return rc;
-  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
-  if (sum) HIPCHK(hipMemcpy(sum, e->d_sum, n_pairs * sizeof(double), hipMemcpyDeviceToHost));
-  if (cnt) HIPCHK(hipMemcpy(cnt, e->d_cnt, n_pairs * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  return NGD_OK;
+  return copy_out(e, 1, e->d_sum, e->d_cnt, sum, cnt);
+}
+
+int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                         uint64_t block_size, void *d_sum, void *d_cnt) {
+  if (!block_maps || !n_rep || !d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_batch_device: null argument");
+  return run_impl(e, block_maps, nullptr, n_rep, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+}
+
+int ngd_run_mult_batch_device(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks,
+                              uint64_t block_size, void *d_sum, void *d_cnt) {
+  if (!mult || !n_rep || !d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_mult_batch_device: null argument");
+  return run_impl(e, nullptr, mult, n_rep, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+}
+
+int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                  double *sum, uint64_t *cnt) {
+  if (!e || !block_maps || !n_rep) return fail(NGD_E_INVALID, "ngd_run_batch: null argument");
+  int rc = batch_buffers(e, n_rep);
+  if (rc) return rc;
+  rc = run_impl(e, block_maps, nullptr, n_rep, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  if (rc) return rc;
+  return copy_out(e, n_rep, e->d_bsum, e->d_bcnt, sum, cnt);
+}
+
+int ngd_run_mult_batch(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                       double *sum, uint64_t *cnt) {
+  if (!e || !mult || !n_rep) return fail(NGD_E_INVALID, "ngd_run_mult_batch: null argument");
+  int rc = batch_buffers(e, n_rep);
+  if (rc) return rc;
+  rc = run_impl(e, nullptr, mult, n_rep, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  if (rc) return rc;
+  return copy_out(e, n_rep, e->d_bsum, e->d_bcnt, sum, cnt);
 }
 
 int ngd_drop_caches(ngd_engine *e) {
   if (!e) return fail(NGD_E_INVALID, "ngd_drop_caches: null engine");
   e->boot_B = 0;
   e->boot_blocks = 0;
+  e->cnt_B = 0;
+  e->cnt_blocks = 0;
   return NGD_OK;
 }
 

@@ -106,10 +106,18 @@ void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, co
 // reduce.hip : deterministic slab reduction + valid-site counting
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
                        const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
-void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                         const double *d_w, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
+uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
+void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
+                         uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
+                         double *d_sum);
+void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
+                         uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
+                         unsigned long long *d_cnt);
+void ngd_launch_count_blocks(hipStream_t st, const ngd_geom &g, const unsigned long long *mask, uint64_t block_size,
+                             uint32_t n_blocks, const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t *C);
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
                       const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles16,
                       uint32_t n_tiles16, unsigned long long *d_cnt);
 void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         unsigned long long value, unsigned long long *d_cnt);
+                         unsigned long long value, const unsigned long long *d_values, uint32_t n_rep,
+                         unsigned long long *d_cnt);

@@ -2,7 +2,9 @@
 // per-pair sums, (2) per-pair valid-site counts for --pairwise_del
 // (reference ngsDist.cpp:335-338 + :362: cnt++ only on sites where neither
 // individual is missing), from bit masks: cnt = popcount(mask_i & mask_j),
-// bootstrap multiplicities entering as bit-planes.
+// bootstrap multiplicities entering as bit-planes, (3) bootstrap replicates
+// as weighted reductions of per-block partial (sum, cnt), many replicates per
+// pass over the partials.
 #include "ngd_internal.h"
 
 namespace {
@@ -29,35 +31,110 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
   d_sum[ngd_pair_idx(n_ind, i, j)] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// Bootstrap replicate from per-block partial sums: sum = SUM_slice w[slice] * slab[slice], slices in
-// ascending order (deterministic).  w = multiplicity of the slice's block in this replicate
-// (reference rnd_map_data, ngsDist.cpp:416-437: a block drawn m times is visited m times).
-__global__ __launch_bounds__(128) void k_reduce_w(const double *__restrict__ slab, uint32_t n_ks,
-                                                   const double *__restrict__ w,
-                                                   const ngd_tile *__restrict__ tiles, uint32_t n_pad,
-                                                   uint64_t n_ind, double *__restrict__ d_sum) {
+// Bootstrap replicates from per-block partial sums, RB replicates per pass over the slab:
+//   sum[r][pair] = SUM_slice W[slice][r] * slab[slice][pair],  slices in ascending order,
+// W = multiplicity of the slice's block in replicate r (reference rnd_map_data, ngsDist.cpp:416-437: a
+// block drawn m times is visited m times).  W is slice-major (stride w_stride, zero padded to a multiple
+// of RB), so the RB weights of a slice are one scalar load; grid.y = replicate chunk.  One order of
+// summation for every replicate and every batch size: a replicate's result does not depend on which
+// call (single or batched) produced it.
+template <int RB>
+__global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ slab, uint32_t n_ks,
+                                                    const double *__restrict__ W, uint32_t w_stride,
+                                                    uint32_t n_rep, const ngd_tile *__restrict__ tiles,
+                                                    uint32_t n_pad, uint64_t n_ind, uint64_t n_pairs,
+                                                    double *__restrict__ d_sum) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
   if (!(i < j && j < n_ind)) return;
+  const uint32_t r0 = blockIdx.y * RB;
   const uint64_t plane = (uint64_t)n_pad * n_pad;
   const double *p = slab + (uint64_t)i * n_pad + j;
-  double s = 0;
-  for (uint32_t ks = 0; ks < n_ks; ks++) {
-    const double wk = w[ks];  // uniform across the workgroup
-    if (wk != 0.0) s += wk * p[ks * plane];
+  const double *w = W + r0;
+  double acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; r++) acc[r] = 0;
+  if (RB == 1) {  // one replicate: about 1/e of the blocks are not drawn at all -> their slices are not read
+    for (uint32_t ks = 0; ks < n_ks; ks++) {
+      const double wk = w[(uint64_t)ks * w_stride];  // uniform across the workgroup
+      if (wk != 0.0) acc[0] = __builtin_fma(wk, p[ks * plane], acc[0]);
+    }
+  } else {
+    constexpr int U = 4;  // slices in flight per thread
+    uint32_t ks = 0;
+    for (; ks + U <= n_ks; ks += U) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = p[(uint64_t)(ks + u) * plane];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)(ks + u) * w_stride + r], v[u], acc[r]);
+    }
+    for (; ks < n_ks; ks++) {
+      const double v = p[(uint64_t)ks * plane];
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)ks * w_stride + r], v, acc[r]);
+    }
   }
-  d_sum[ngd_pair_idx(n_ind, i, j)] = s;
+  const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+#pragma unroll
+  for (int r = 0; r < RB; r++)
+    if (r0 + r < n_rep) d_sum[(uint64_t)(r0 + r) * n_pairs + idx] = acc[r];
 }
 
-__global__ __launch_bounds__(128) void k_fill_cnt(const ngd_tile *__restrict__ tiles, uint64_t n_ind,
-                                                   unsigned long long value,
-                                                   unsigned long long *__restrict__ d_cnt) {
+// The same for the valid-site counts of --pairwise_del: cnt[r][pair] = SUM_b M[b][r] * C[b][pair] with
+// C = per-block popcounts (k_count_blocks) and M the block multiplicities (uint32, block-major).
+template <int RB>
+__global__ __launch_bounds__(128) void k_reduce_cb(const uint32_t *__restrict__ C, uint32_t n_blocks,
+                                                    const uint32_t *__restrict__ M, uint32_t m_stride,
+                                                    uint32_t n_rep, const ngd_tile *__restrict__ tiles,
+                                                    uint32_t n_pad, uint64_t n_ind, uint64_t n_pairs,
+                                                    unsigned long long *__restrict__ d_cnt) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
   if (!(i < j && j < n_ind)) return;
-  d_cnt[ngd_pair_idx(n_ind, i, j)] = value;
+  const uint32_t r0 = blockIdx.y * RB;
+  const uint64_t plane = (uint64_t)n_pad * n_pad;
+  const uint32_t *p = C + (uint64_t)i * n_pad + j;
+  const uint32_t *m = M + r0;
+  unsigned long long acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; r++) acc[r] = 0;
+  constexpr int U = 4;
+  uint32_t b = 0;
+  for (; b + U <= n_blocks; b += U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = p[(uint64_t)(b + u) * plane];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] += (unsigned long long)m[(uint64_t)(b + u) * m_stride + r] * v[u];
+  }
+  for (; b < n_blocks; b++) {
+    const uint32_t v = p[(uint64_t)b * plane];
+#pragma unroll
+    for (int r = 0; r < RB; r++) acc[r] += (unsigned long long)m[(uint64_t)b * m_stride + r] * v;
+  }
+  const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+#pragma unroll
+  for (int r = 0; r < RB; r++)
+    if (r0 + r < n_rep) d_cnt[(uint64_t)(r0 + r) * n_pairs + idx] = acc[r];
+}
+
+// grid.y = replicate: cnt[r][pair] = values[r] (no --pairwise_del: every visited site counts, ngsDist.cpp:362)
+__global__ __launch_bounds__(128) void k_fill_cnt(const ngd_tile *__restrict__ tiles, uint64_t n_ind,
+                                                   unsigned long long value,
+                                                   const unsigned long long *__restrict__ values,
+                                                   uint64_t n_pairs, unsigned long long *__restrict__ d_cnt) {
+  const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
+  const uint32_t i = tiles[tile].ti * NGD_TILE + row;
+  const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
+  if (!(i < j && j < n_ind)) return;
+  d_cnt[(uint64_t)blockIdx.y * n_pairs + ngd_pair_idx(n_ind, i, j)] = values ? values[blockIdx.y] : value;
 }
 
 constexpr int CW = 64;  // mask words staged per step
@@ -101,6 +178,60 @@ __global__ __launch_bounds__(256) void k_count(const unsigned long long *__restr
   if (i < j && j < n_ind) d_cnt[ngd_pair_idx(n_ind, i, j)] = cnt;
 }
 
+// Per-block valid-site counts C[b][i][j] = popcount(mask_i & mask_j over the sites of block b): the cnt half
+// of the per-block partials.  Workgroup = 16x16 pairs; grid.y strides over the blocks.  A block is any
+// site range [b*B, (b+1)*B), so its first and last mask words are trimmed.
+__global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long *__restrict__ mask,
+                                                       uint32_t n_words, uint64_t block_size, uint32_t n_blocks,
+                                                       const ngd_tile *__restrict__ tiles, uint32_t n_pad,
+                                                       uint64_t n_ind, uint32_t *__restrict__ C) {
+  __shared__ unsigned long long mi[16][CW + 1], mj[16][CW + 1];
+  const uint32_t ig = tiles[blockIdx.x].ti, jg = tiles[blockIdx.x].tj;
+  const uint32_t ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const uint32_t i = ig * 16 + ty, j = jg * 16 + tx;
+  for (uint32_t b = blockIdx.y; b < n_blocks; b += gridDim.y) {
+    const uint64_t s_lo = (uint64_t)b * block_size, s_hi = s_lo + block_size;  // sites [s_lo, s_hi)
+    const uint32_t w_lo = (uint32_t)(s_lo >> 6), w_hi = (uint32_t)((s_hi - 1) >> 6);
+    uint32_t cnt = 0;
+    for (uint32_t w0 = w_lo; w0 <= w_hi; w0 += CW) {
+      for (uint32_t t = threadIdx.x; t < 16 * CW; t += 256) {
+        const uint32_t r = t / CW, c = t % CW;
+        const uint32_t w = w0 + c;
+        unsigned long long keep = 0;
+        if (w <= w_hi) {
+          keep = ~0ull;
+          if (w == w_lo) keep &= ~0ull << (s_lo & 63);
+          if (w == w_hi && (s_hi & 63)) keep &= ~0ull >> (64 - (s_hi & 63));
+        }
+        const uint32_t ii = ig * 16 + r, jj = jg * 16 + r;
+        mi[r][c] = (keep && ii < n_ind) ? mask[(uint64_t)ii * n_words + w] & keep : 0ull;
+        mj[r][c] = (keep && jj < n_ind) ? mask[(uint64_t)jj * n_words + w] : 0ull;
+      }
+      __syncthreads();
+      const uint32_t left = w_hi - w0 + 1;
+      const uint32_t nw = left < (uint32_t)CW ? left : (uint32_t)CW;
+      for (uint32_t c = 0; c < nw; c++) cnt += __popcll(mi[ty][c] & mj[tx][c]);
+      __syncthreads();
+    }
+    C[((uint64_t)b * n_pad + i) * n_pad + j] = cnt;
+  }
+}
+
+template <int RB>
+void reduce_wb(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
+               uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
+  hipLaunchKernelGGL((k_reduce_wb<RB>), dim3(n_tiles * NGD_TILE, (n_rep + RB - 1) / RB), dim3(128), 0, st, slab,
+                     n_ks, d_W, w_stride, n_rep, d_tiles, g.n_pad, g.n_ind, g.n_ind * (g.n_ind - 1) / 2, d_sum);
+}
+
+template <int RB>
+void reduce_cb(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
+               uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
+               unsigned long long *d_cnt) {
+  hipLaunchKernelGGL((k_reduce_cb<RB>), dim3(n_tiles * NGD_TILE, (n_rep + RB - 1) / RB), dim3(128), 0, st, C,
+                     n_blocks, d_M, m_stride, n_rep, d_tiles, g.n_pad, g.n_ind, g.n_ind * (g.n_ind - 1) / 2, d_cnt);
+}
+
 }  // namespace
 
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
@@ -110,18 +241,46 @@ void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, ui
                      g.n_ind, d_sum);
 }
 
-void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                         const double *d_w, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
-  if (!n_tiles) return;
-  hipLaunchKernelGGL(k_reduce_w, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, d_w, d_tiles, g.n_pad,
-                     g.n_ind, d_sum);
+// replicates per pass over the partials; the weight arrays are padded to a multiple of it
+uint32_t ngd_reduce_chunk(uint32_t n_rep) { return n_rep <= 1 ? 1 : n_rep <= 4 ? 4 : n_rep <= 16 ? 16 : 32; }
+
+void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
+                         uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
+                         double *d_sum) {
+  if (!n_tiles || !n_rep) return;
+  switch (ngd_reduce_chunk(n_rep)) {
+    case 1: reduce_wb<1>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
+    case 4: reduce_wb<4>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
+    case 16: reduce_wb<16>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
+    default: reduce_wb<32>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum);
+  }
+}
+
+void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
+                         uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
+                         unsigned long long *d_cnt) {
+  if (!n_tiles || !n_rep) return;
+  switch (ngd_reduce_chunk(n_rep)) {
+    case 1: reduce_cb<1>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;
+    case 4: reduce_cb<4>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;
+    case 16: reduce_cb<16>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;
+    default: reduce_cb<32>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt);
+  }
+}
+
+void ngd_launch_count_blocks(hipStream_t st, const ngd_geom &g, const unsigned long long *mask, uint64_t block_size,
+                             uint32_t n_blocks, const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t *C) {
+  if (!n_tiles16 || !n_blocks) return;
+  hipLaunchKernelGGL(k_count_blocks, dim3(n_tiles16, n_blocks < 1024 ? n_blocks : 1024), dim3(256), 0, st, mask,
+                     g.n_words, block_size, n_blocks, d_tiles16, g.n_pad, g.n_ind, C);
 }
 
 void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         unsigned long long value, unsigned long long *d_cnt) {
-  if (!n_tiles) return;
-  hipLaunchKernelGGL(k_fill_cnt, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, d_tiles, g.n_ind, value,
-                     d_cnt);
+                         unsigned long long value, const unsigned long long *d_values, uint32_t n_rep,
+                         unsigned long long *d_cnt) {
+  if (!n_tiles || !n_rep) return;
+  hipLaunchKernelGGL(k_fill_cnt, dim3(n_tiles * NGD_TILE, n_rep), dim3(128), 0, st, d_tiles, g.n_ind, value,
+                     d_values, g.n_ind * (g.n_ind - 1) / 2, d_cnt);
 }
 
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,

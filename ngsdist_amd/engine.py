@@ -145,6 +145,31 @@ class Engine:
                                     c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
+    def run_batch(self, block_maps=None, block_size=1, mult=None, d_sum_ptr=None, d_cnt_ptr=None):
+        """n_rep bootstrap replicates in one call (ngd_run_batch / ngd_run_mult_batch): block_maps or mult is
+        [n_rep][n_blocks]; returns (sum, cnt) of shape [n_rep][n_pairs], or writes them to device buffers."""
+        if (block_maps is None) == (mult is None):
+            raise ValueError("give block_maps or mult")
+        if mult is None:
+            a = np.ascontiguousarray(block_maps, dtype=np.uint64)
+            ap = a.ctypes.data_as(C.POINTER(C.c_uint64))
+            f_host, f_dev = self._L.ngd_run_batch, self._L.ngd_run_batch_device
+        else:
+            a = np.ascontiguousarray(mult, dtype=np.uint32)
+            ap = a.ctypes.data_as(C.POINTER(C.c_uint32))
+            f_host, f_dev = self._L.ngd_run_mult_batch, self._L.ngd_run_mult_batch_device
+        if a.ndim != 2:
+            raise ValueError("expected [n_rep][n_blocks]")
+        n_rep, n_blocks = a.shape
+        if d_sum_ptr is not None:
+            _check(f_dev(self._h, ap, n_rep, n_blocks, int(block_size), C.c_void_p(d_sum_ptr), C.c_void_p(d_cnt_ptr)))
+            return None
+        s = np.empty((n_rep, self.n_pairs), dtype=np.float64)
+        c = np.empty((n_rep, self.n_pairs), dtype=np.uint64)
+        _check(f_host(self._h, ap, n_rep, n_blocks, int(block_size), s.ctypes.data_as(C.POINTER(C.c_double)),
+                      c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return s, c
+
     def run_device(self, d_sum_ptr, d_cnt_ptr, block_map=None, block_size=1):
         """Results written to caller-owned device buffers (raw addresses)."""
         ptr, nb, bs, keep = self._map_args(block_map, block_size)

@@ -179,6 +179,56 @@ def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkey
         assert e.timing()["launches"] == 1
 
 
+@pytest.mark.parametrize("kernel,block_size,pdel", [("mfma", 8, True), ("mfma", 100, False), ("mfma", 7, True),
+                                                    ("stream", 10, True), ("em_fast", 5, True),
+                                                    ("em_faithful", 12, False)])
+@pytest.mark.parametrize("n_rep", [1, 3, 21, 37])
+def test_bootstrap_batch(kernel, block_size, pdel, n_rep):
+    """ngd_run_batch: n_rep replicates in one call == the same replicates one ngd_run at a time (identical
+    bits: one summation order for every batch size), each within tolerance of the oracle; covers the
+    per-block partial path (mfma with B % 4 == 0, EM) and the per-replicate fallback (mfma B = 7, stream)."""
+    n_ind, n_sites = 37, 1501
+    indep = kernel in INDEP_KERNELS
+    p = O.synth_indmajor(23, n_ind, n_sites, miss_frac=0.2)
+    rng = N().Taus(99)
+    n_eff = n_sites - n_sites % block_size
+    maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)])
+    with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_batch(maps, block_size)
+        assert S.shape == (n_rep, e.n_pairs) and Cn.shape == (n_rep, e.n_pairs)
+        for r in range(n_rep):
+            s1, c1 = e.run(maps[r], block_size)
+            assert np.array_equal(Cn[r], c1)
+            assert np.array_equal(S[r], s1)
+        # the same replicates as multiplicities (site-sharding entry point)
+        mult = np.stack([np.bincount(m.astype(np.int64), minlength=maps.shape[1]) for m in maps]).astype(np.uint32)
+        S2, C2 = e.run_batch(mult=mult, block_size=block_size)
+        assert np.array_equal(S2, S) and np.array_equal(C2, Cn)
+    for r in sorted({0, n_rep - 1}):
+        so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=indep, site_src=O.boot_site_src(maps[r], block_size),
+                             n_sites=n_eff, n_threads=8)
+        assert np.array_equal(Cn[r], co)
+        assert rel_err(S[r], so) < RTOL
+
+
+def test_bootstrap_batch_called_genotypes_bit_exact():
+    """called genotypes: every replicate of a batch is exactly the oracle's sum (dyadic terms)."""
+    rng = np.random.default_rng(5)
+    n_ind, n_sites, B = 30, 4000, 40
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    t = N().Taus(7)
+    maps = np.stack([t.block_map(n_sites // B) for _ in range(10)])
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_batch(maps, B)
+    for r in (0, 9):
+        so, co = O.all_pairs(p, site_src=O.boot_site_src(maps[r], B), n_sites=n_sites, n_threads=8)
+        assert np.array_equal(S[r], so) and np.array_equal(Cn[r], co)
+
+
 def test_heavy_multiplicity_counts():
     """all blocks map to block 0 -> multiplicity n_blocks on a few sites (bit-plane path)."""
     n_ind, n_sites, B = 5, 640, 2
