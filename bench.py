@@ -125,37 +125,71 @@ def main():
              for m in maps]
 
     cnt_full = np.full(n_pairs, n_sites, dtype=np.uint64)
-    cnt_boot = np.full(n_pairs, n_eff, dtype=np.uint64)
     acc_ms, red_ms, tot_ms, pair_sites = [], [], [], []
     last = {}
 
+    # Bootstrap workloads: all replicates of the job go to the engine in ONE call (ngd_run_mult_batch: per-block
+    # partial sums once, then every replicate is a weighted reduction of them).  When the blocks cover the
+    # whole data set the full-data matrix is the all-ones row of the same batch, otherwise it is its own pass.
+    batched = W["n_boot"] > 0
+    if batched:
+        n_blocks = n_eff // W["block"]
+        fold0 = n_eff == n_sites
+        rows = ([np.ones(n_blocks, dtype=np.uint32)] if fold0 else []) + mults[1:]
+        mult_all = np.ascontiguousarray(np.stack(rows)[:, blk_lo:blk_hi] if by_sites else np.stack(rows))
+        d_all = torch.zeros((n_mat, n_pairs), dtype=torch.float64, device=dev)
+        d_call = torch.zeros((n_mat, n_pairs), dtype=torch.int64, device=dev)
+        h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
+        cnt_all = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
+        cnt_all[0, :] = n_sites
+
+    def record_timing():
+        t = eng.timing()
+        red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
+        if t["launches"]:  # replicates served from cached block partial sums launch no accumulation
+            acc_ms.append(t["ms_accum"] / t["launches"]); pair_sites.append(t["pair_sites"] / t["launches"])
+
     def step(record):
         eng.drop_caches()  # bootstrap block partial sums are recomputed in every step (no carried work)
-        for rep in range(n_mat):
-            if by_sites and maps[rep] is not None:
-                eng.run_mult(mults[rep][blk_lo:blk_hi], W["block"], d_sum.data_ptr(), d_cnt.data_ptr())
-            else:
-                eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rep], W["block"])
+        if batched:
+            first = 0 if fold0 else 1
+            if not fold0:
+                eng.run_device(d_all[0].data_ptr(), d_call[0].data_ptr())
+                if record:
+                    record_timing()
+            eng.run_batch(mult=mult_all, block_size=W["block"], d_sum_ptr=d_all[first].data_ptr(),
+                          d_cnt_ptr=d_call[first].data_ptr())
             if record:
-                t = eng.timing()
-                red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
-                if t["launches"]:  # a replicate served from block partial sums launches no accumulation
-                    acc_ms.append(t["ms_accum"]); pair_sites.append(t["pair_sites"])
-            # no --pairwise_del in these workloads: every pair's count is the number of sites visited,
-            # so only the sums travel (one collective); rank 0 fills the counts in.
+                record_timing()
             if args.backend == "nccl":
-                merge_shards(d_sum, None, dst=0)  # ONE RCCL collective; shards are disjoint
+                merge_shards(d_all, None, dst=0)  # ONE RCCL collective for the whole job
                 if rank == 0:
-                    h_sum.copy_(d_sum, non_blocking=True)
+                    h_all.copy_(d_all, non_blocking=True)
                     torch.cuda.synchronize()
-            else:  # rehearsal: merge on the host over gloo
-                h_sum.copy_(d_sum)
-                merge_shards(h_sum, None, dst=0)
-            if rank == 0:
-                cnt_np = cnt_boot if maps[rep] is not None else cnt_full
+            else:
+                h_all.copy_(d_all)
+                merge_shards(h_all, None, dst=0)
             if rank == 0:
                 with np.errstate(all="ignore"):
-                    last["dist"] = N.finish(h_sum.numpy(), cnt_np, 0, W["evol_model"])
+                    last["dist"] = N.finish(h_all.numpy().reshape(-1), cnt_all.reshape(-1), 0,
+                                            W["evol_model"])[-n_pairs:]
+            return
+        eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr())
+        if record:
+            record_timing()
+        # no --pairwise_del in these workloads: every pair's count is the number of sites visited,
+        # so only the sums travel (one collective); rank 0 fills the counts in.
+        if args.backend == "nccl":
+            merge_shards(d_sum, None, dst=0)  # ONE RCCL collective; shards are disjoint / partial sums add
+            if rank == 0:
+                h_sum.copy_(d_sum, non_blocking=True)
+                torch.cuda.synchronize()
+        else:  # rehearsal: merge on the host over gloo
+            h_sum.copy_(d_sum)
+            merge_shards(h_sum, None, dst=0)
+        if rank == 0:
+            with np.errstate(all="ignore"):
+                last["dist"] = N.finish(h_sum.numpy(), cnt_full, 0, W["evol_model"])
 
     def fence():
         if world > 1:
@@ -169,9 +203,9 @@ def main():
 
     if world > 1:  # communicator and buffers come up outside the timed region whatever --warmup is
         if args.backend == "nccl":
-            merge_shards(d_sum, None, dst=0)
+            merge_shards(d_all if batched else d_sum, None, dst=0)
         else:
-            merge_shards(h_sum, None, dst=0)
+            merge_shards(h_all if batched else h_sum, None, dst=0)
     for _ in range(args.warmup):
         step(False)
     fence()

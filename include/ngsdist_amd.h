@@ -198,6 +198,16 @@ int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs,
                uint64_t tot_sites, uint64_t evol_model, double *dist);
 
+/* The print block of one matrix, ngsDist.cpp:282-287 with join() gen_func.cpp:479-496:
+ * "\n<n_ind>\n", then per individual its label and n_ind cells "\t%.10f", newline.  `dist` is
+ * ngd_finish()'s output (pair order); the matrix is its symmetric expansion with a zero diagonal
+ * (dist_matrix, ngsDist.cpp:200,:411).  Cells are formatted exactly as printf's "%.10f" does
+ * (-0.0000000000, inf, nan, -nan included), rows in parallel on n_threads host threads (0 = auto).
+ * Returns the number of bytes of the block (no terminator); they are written to `out` only if
+ * cap is large enough (call with out = NULL to size), or a negative NGD_E_* code. */
+int64_t ngd_format_matrix(const double *dist, uint64_t n_ind, const char *const *labels, char *out,
+                          uint64_t cap, uint32_t n_threads);
+
 /* Bootstrap block map exactly as the reference draws it (gsl_rng_taus seeded
  * with --seed, ngsDist.cpp:179-180; one draw per block, :421-423).  The state
  * is three uint32 carried across replicates by the caller. */

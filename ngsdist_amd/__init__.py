@@ -5,8 +5,8 @@ host driver) and this thin ctypes door.  Importing the package does not load
 the library; the first Engine()/finish()/Taus() does, and fails loudly if the
 HIP engine was not built.
 """
-from .engine import (DEFAULT_SCORE, KERNELS, Engine, NgdError, Taus, device_count, finish, n_pairs,
+from .engine import (DEFAULT_SCORE, KERNELS, Engine, NgdError, Taus, device_count, finish, format_matrix, n_pairs,
                      score_matrix)
 
-__all__ = ["Engine", "NgdError", "Taus", "finish", "device_count", "n_pairs", "score_matrix",
+__all__ = ["Engine", "NgdError", "Taus", "finish", "format_matrix", "device_count", "n_pairs", "score_matrix",
            "DEFAULT_SCORE", "KERNELS"]

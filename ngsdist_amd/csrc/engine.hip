@@ -685,7 +685,6 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));  // W, M, drawn are host temporaries
   read_timing(e, n_eff, launches, false);
-  e->timing.pair_sites = e->n_owned_pairs * n_eff * n_rep;
   return NGD_OK;
 }
 

@@ -543,7 +543,7 @@ int main(int argc, char **argv) {
   if (p.verbose >= 2)
     fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident per device)\n", t_load,
             (double)p.n_ind * p.n_sites * 24 / 1e9);
-  double t_compute = 0;
+  double t_compute = 0, t_write = 0;
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];
@@ -552,85 +552,105 @@ int main(int argc, char **argv) {
   FILE *out_fh = fopen(p.out, "w");
   if (!out_fh) die(__FUNCTION__, "cannot open output file!");
 
-  std::vector<double> sum(n_comb), part(n_comb), dist(n_comb);
-  std::vector<uint64_t> cnt(n_comb), cpart(n_comb), block_map;
-  std::vector<double> matrix(p.n_ind * p.n_ind, 0.0);  // zero diagonal, reused across replicates (:200)
-  std::string row;
+  // Replicates go to the engine in batches (ngd_run_batch): the block maps of a batch are drawn up front, in
+  // the order rnd_map_data (ngsDist.cpp:416-437) would draw them -- nothing else consumes the generator.
+  const uint64_t kBatch = 32;
+  std::vector<double> sum, dist(n_comb);
+  std::vector<uint64_t> cnt, block_maps;
+  std::vector<const char *> label_ptr;
+  for (auto &l : labels) label_ptr.push_back(l.c_str());
+  std::vector<char> text;
   uint64_t n_sites = p.n_sites;
 
-  fflush(stdout);
-  for (uint64_t rep = 0; rep <= p.n_boot_rep; rep++) {
-    if (p.verbose >= 1) {
-      if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
-      else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
+  // all engines, one host thread each; shards are disjoint, so merging is x + 0
+  auto run_all = [&](const uint64_t *maps, uint32_t n_rep, uint64_t n_blocks) {
+    const uint64_t n_mat = n_rep ? n_rep : 1;
+    sum.assign(n_mat * n_comb, 0.0);
+    cnt.assign(n_mat * n_comb, 0);
+    auto run_one = [&](size_t r, double *s, uint64_t *c) {
+      return n_rep ? ngd_run_batch(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c)
+                   : ngd_run(eng.e[r], nullptr, 0, 0, s, c);
+    };
+    if (eng.e.size() == 1) {
+      int rc = run_one(0, sum.data(), cnt.data());
+      if (rc) die_engine(n_rep ? "ngd_run_batch" : "ngd_run", rc);
+      return;
     }
-    if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
-    const uint64_t *bm = nullptr;
-    uint64_t n_blocks = 0;
+    std::vector<std::vector<double>> ps(eng.e.size(), std::vector<double>(n_mat * n_comb));
+    std::vector<std::vector<uint64_t>> pc(eng.e.size(), std::vector<uint64_t>(n_mat * n_comb));
+    std::vector<int> rcs(eng.e.size(), 0);
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < eng.e.size(); r++)
+      th.emplace_back([&, r]() { rcs[r] = run_one(r, ps[r].data(), pc[r].data()); });
+    for (auto &t : th) t.join();
+    for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine(n_rep ? "ngd_run_batch" : "ngd_run", rcs[r]);
+    for (size_t r = 0; r < eng.e.size(); r++)
+      for (uint64_t k = 0; k < n_mat * n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
+  };
+
+  fflush(stdout);
+  for (uint64_t rep = 0; rep <= p.n_boot_rep;) {
+    uint64_t n_blocks = 0, n_in_batch = 1;
+    const auto t_c0 = std::chrono::steady_clock::now();
     if (rep > 0) {  // ngsDist.cpp:235-238
       n_sites -= n_sites % p.boot_block_size;
       n_blocks = n_sites / p.boot_block_size;
-      block_map.resize(n_blocks);
-      ngd_boot_block_map(rng, n_blocks, block_map.data());
-      bm = block_map.data();
-      if (p.verbose >= 5)
+      n_in_batch = std::min<uint64_t>(kBatch, p.n_boot_rep - rep + 1);
+      block_maps.resize(n_in_batch * n_blocks);
+      for (uint64_t r = 0; r < n_in_batch; r++) ngd_boot_block_map(rng, n_blocks, &block_maps[r * n_blocks]);
+      run_all(block_maps.data(), (uint32_t)n_in_batch, n_blocks);
+    } else {
+      run_all(nullptr, 0, 0);
+    }
+    t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
+
+    for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
+      // the reference's progress lines, in its order (:218-241, :281)
+      if (p.verbose >= 1) {
+        if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
+        else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
+      }
+      if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
+      if (rep > 0 && p.verbose >= 5) {
+        const uint64_t *bm = &block_maps[r * n_blocks];
         for (uint64_t b = 0; b < n_blocks; b++)
           for (uint64_t s = 0; s < p.boot_block_size; s++)
             fprintf(stderr, "block: %lu\torig_site: %lu\trand_block:%lu\trand_site: %lu\n", b,
-                    b * p.boot_block_size + s, block_map[b], block_map[b] * p.boot_block_size + s);
-    }
-    if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
-    const auto t_c0 = std::chrono::steady_clock::now();
-    if (eng.e.size() == 1) {
-      int rc = ngd_run(eng.e[0], bm, n_blocks, p.boot_block_size, sum.data(), cnt.data());
-      if (rc) die_engine("ngd_run", rc);
-    } else {
-      // one host thread per device; shards are disjoint, so merging is x + 0
-      std::vector<std::vector<double>> ps(eng.e.size(), std::vector<double>(n_comb));
-      std::vector<std::vector<uint64_t>> pc(eng.e.size(), std::vector<uint64_t>(n_comb));
-      std::vector<int> rcs(eng.e.size(), 0);
-      std::vector<std::thread> th;
-      for (size_t r = 0; r < eng.e.size(); r++)
-        th.emplace_back([&, r]() { rcs[r] = ngd_run(eng.e[r], bm, n_blocks, p.boot_block_size, ps[r].data(), pc[r].data()); });
-      for (auto &t : th) t.join();
-      for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine("ngd_run", rcs[r]);
-      std::fill(sum.begin(), sum.end(), 0.0);
-      std::fill(cnt.begin(), cnt.end(), 0);
-      for (size_t r = 0; r < eng.e.size(); r++)
-        for (uint64_t k = 0; k < n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
-    }
-    if (p.verbose >= 3) {  // the per-pair line of ngsDist.cpp:366-367
-      uint64_t k = 0;
-      for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
-        for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
-          fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
-                  sum[k], cnt[k], sum[k] / (double)cnt[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
-    }
-    int rc = ngd_finish(sum.data(), cnt.data(), n_comb, p.tot_sites, p.evol_model, dist.data());
-    if (rc) die("gen_dist", "invalid evolutionary model specified!");
-    t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
-    uint64_t k = 0;
-    for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
-      for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
-        matrix[i1 * p.n_ind + i2] = matrix[i2 * p.n_ind + i1] = dist[k];  // gen_dist_slave, :408-412
-
-    if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
-    fprintf(out_fh, "\n%lu\n", p.n_ind);  // ngsDist.cpp:282-287
-    char cell[64];
-    for (uint64_t i = 0; i < p.n_ind; i++) {
-      row.assign(labels[i]);
-      for (uint64_t j = 0; j < p.n_ind; j++) {
-        snprintf(cell, sizeof(cell), "\t%.10f", matrix[i * p.n_ind + j]);  // join(), gen_func.cpp:479-496
-        row += cell;
+                    b * p.boot_block_size + s, bm[b], bm[b] * p.boot_block_size + s);
       }
-      row += '\n';
-      fwrite(row.data(), 1, row.size(), out_fh);
+      if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
+      const double *rs = &sum[r * n_comb];
+      const uint64_t *rc_ = &cnt[r * n_comb];
+      if (p.verbose >= 3) {  // the per-pair line of ngsDist.cpp:366-367
+        uint64_t k = 0;
+        for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
+          for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
+            fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
+                    rs[k], rc_[k], rs[k] / (double)rc_[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
+      }
+      const auto t_f0 = std::chrono::steady_clock::now();
+      int rc = ngd_finish(rs, rc_, n_comb, p.tot_sites, p.evol_model, dist.data());
+      if (rc) die("gen_dist", "invalid evolutionary model specified!");
+      t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
+
+      if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
+      // ngsDist.cpp:282-287 (join(), gen_func.cpp:479-496); rows formatted in parallel, same bytes
+      const auto t_w0 = std::chrono::steady_clock::now();
+      if (text.empty()) text.resize(64 + p.n_ind * (p.n_ind * 16 + 64));
+      int64_t need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+      if (need > (int64_t)text.size()) {
+        text.resize((size_t)need);
+        need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+      }
+      if (need < 0) die(__FUNCTION__, "cannot format the distance matrix");
+      if (fwrite(text.data(), 1, (size_t)need, out_fh) != (size_t)need) die(__FUNCTION__, "cannot write output file!");
+      t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
     }
   }
   fclose(out_fh);
   if (p.verbose >= 2)
-    fprintf(stderr, "> distances: %.3f s for %lu matri%s of %lu pairs\n", t_compute, p.n_boot_rep + 1,
-            p.n_boot_rep ? "ces" : "x", n_comb);
+    fprintf(stderr, "> distances: %.3f s for %lu matri%s of %lu pairs; formatting + writing them: %.3f s\n", t_compute,
+            p.n_boot_rep + 1, p.n_boot_rep ? "ces" : "x", n_comb, t_write);
   if (p.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
   if (p.verbose >= 1) fprintf(stderr, "Done!\n");
   return 0;

@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -43,7 +46,88 @@ static void finish_range(const double *sum, const uint64_t *cnt, uint64_t lo, ui
   }
 }
 
+// "%.10f" of one cell, byte-for-byte what printf writes (the reference formats every cell with
+// snprintf("%.10f"), gen_func.cpp:483-486), without going through printf's arbitrary-precision path:
+// x = m * 2^q exactly, so round-half-even(x * 10^10) is an integer computed exactly in 128 bits
+// (m < 2^53, 10^10 < 2^34); printf rounds the exact binary value the same way (round-to-nearest mode).
+// Values of 2^29 and above, which no distance reaches, and non-finite cells go to snprintf itself.
+static inline char *fmt_fixed10(double x, char *o) {
+  uint64_t bits;
+  memcpy(&bits, &x, 8);
+  const int e = (int)((bits >> 52) & 0x7FF);
+  uint64_t m = bits & ((1ull << 52) - 1);
+  if (e >= 1023 + 29) return o + snprintf(o, 400, "%.10f", x);  // large, inf, nan
+  if (bits >> 63) *o++ = '-';
+  int q;  // x = m * 2^q
+  if (e == 0) q = -1074;
+  else { m |= 1ull << 52; q = e - 1075; }
+  const unsigned __int128 P = (unsigned __int128)m * 10000000000ull;
+  uint64_t N;
+  const int sh = -q;  // e < 1052 -> q < 0
+  if (sh >= 100) N = 0;  // P < 2^87: below one half of the last digit
+  else {
+    N = (uint64_t)(P >> sh);
+    const unsigned __int128 rem = P & (((unsigned __int128)1 << sh) - 1), half = (unsigned __int128)1 << (sh - 1);
+    if (rem > half || (rem == half && (N & 1))) N++;
+  }
+  const uint64_t ip = N / 10000000000ull;
+  uint64_t fp = N % 10000000000ull;
+  char tmp[24];
+  int n = 0;
+  uint64_t v = ip;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *o++ = tmp[--n];
+  *o++ = '.';
+  for (int d = 9; d >= 0; d--) { o[d] = (char)('0' + fp % 10); fp /= 10; }
+  return o + 10;
+}
+
 extern "C" {
+
+// The print block of one matrix, ngsDist.cpp:282-287: "\n<n_ind>\n", then per individual its label and
+// n_ind cells "\t%.10f" (join(), gen_func.cpp:479-496) and a newline.  Rows are formatted by threads.
+int64_t ngd_format_matrix(const double *dist, uint64_t n_ind, const char *const *labels, char *out, uint64_t cap,
+                          uint32_t n_threads) {
+  if (!dist || !labels || n_ind < 2) return NGD_E_INVALID;
+  unsigned nt = n_threads ? n_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (n_ind < 64) nt = 1;
+  nt = (unsigned)std::min<uint64_t>(nt, n_ind);
+  std::vector<std::string> part(nt);
+  auto rows = [&](unsigned t) {
+    const uint64_t lo = n_ind * t / nt, hi = n_ind * (t + 1) / nt;
+    std::string &s = part[t];
+    s.reserve((hi - lo) * (n_ind * 14 + 32));
+    char cell[416];
+    for (uint64_t i = lo; i < hi; i++) {
+      s += labels[i];
+      for (uint64_t j = 0; j < n_ind; j++) {
+        // dist_matrix is symmetric with a zero diagonal (gen_dist_slave :411, init_ptr :200)
+        const double d = i == j ? 0.0 : i < j ? dist[i * (2 * n_ind - i - 1) / 2 + (j - i - 1)]
+                                              : dist[j * (2 * n_ind - j - 1) / 2 + (i - j - 1)];
+        cell[0] = '\t';
+        char *end = fmt_fixed10(d, cell + 1);
+        s.append(cell, (size_t)(end - cell));
+      }
+      s += '\n';
+    }
+  };
+  if (nt == 1) rows(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(rows, t);
+    for (auto &t : th) t.join();
+  }
+  char head[32];
+  const int hn = snprintf(head, sizeof(head), "\n%lu\n", (unsigned long)n_ind);
+  uint64_t total = (uint64_t)hn;
+  for (auto &s : part) total += s.size();
+  if (out && cap >= total) {
+    memcpy(out, head, (size_t)hn);
+    char *o = out + hn;
+    for (auto &s : part) { memcpy(o, s.data(), s.size()); o += s.size(); }
+  }
+  return (int64_t)total;
+}
 
 void ngd_taus_seed(uint32_t st[3], uint64_t seed) {
   uint32_t s = (uint32_t)seed;

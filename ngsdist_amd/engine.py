@@ -199,6 +199,26 @@ def finish(sum_, cnt, tot_sites=0, evol_model=1):
     return out
 
 
+def format_matrix(dist, labels, n_threads=0):
+    """The print block of one matrix (ngsDist.cpp:282-287) as bytes, from ngd_finish()'s pair-ordered output."""
+    L = _lib.load()
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    n_ind = len(labels)
+    if d.size != n_ind * (n_ind - 1) // 2:
+        raise ValueError("dist must hold n_ind*(n_ind-1)/2 cells")
+    lab = (C.c_char_p * n_ind)(*[x.encode() if isinstance(x, str) else x for x in labels])
+    dp = d.ctypes.data_as(C.POINTER(C.c_double))
+    cap = 32 + sum(len(x) + 1 for x in lab) + n_ind * n_ind * 16  # enough unless cells are huge
+    while True:
+        buf = C.create_string_buffer(cap)
+        need = L.ngd_format_matrix(dp, n_ind, lab, buf, cap, int(n_threads))
+        if need < 0:
+            _check(int(need))
+        if need <= cap:
+            return buf.raw[:need]
+        cap = int(need)
+
+
 class Taus:
     """gsl_rng_taus as the reference seeds and draws it (ngsDist.cpp:179-180, :421-423)."""
 
