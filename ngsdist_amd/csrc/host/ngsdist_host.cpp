@@ -228,6 +228,50 @@ static std::vector<std::string> read_lines(const char *path, uint64_t offset) {
   return out;
 }
 
+// strtod for the common spelling [-+]digits[.digits][e[-+]digits], exactly: up to 19 significant digits are
+// gathered in an integer; when it is below 2^53 and the decimal exponent within +-22 the value is one
+// correctly rounded multiplication or division by an exact power of ten (Clinger's fast path), which is what a
+// correctly rounding strtod returns too.  Anything else (more digits, nan, inf, hex, junk) goes to strtod.
+static inline bool fast_strtod(const char *s, size_t len, double *out) {
+  static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char *p = s, *end = s + len;
+  bool neg = false;
+  if (p < end && (*p == '-' || *p == '+')) neg = *p++ == '-';
+  uint64_t m = 0;
+  int nd = 0, e10 = 0;
+  bool any = false;
+  for (; p < end && *p >= '0' && *p <= '9'; p++) {
+    any = true;
+    if (m || *p != '0') { if (++nd > 19) return false; m = m * 10 + (uint64_t)(*p - '0'); }
+  }
+  if (p < end && *p == '.') {
+    for (p++; p < end && *p >= '0' && *p <= '9'; p++) {
+      any = true;
+      if (m || *p != '0') { if (++nd > 19) return false; m = m * 10 + (uint64_t)(*p - '0'); }
+      e10--;
+    }
+  }
+  if (!any) return false;
+  if (p < end && (*p == 'e' || *p == 'E')) {
+    p++;
+    bool eneg = false;
+    if (p < end && (*p == '-' || *p == '+')) eneg = *p++ == '-';
+    if (p >= end) return false;
+    int ex = 0;
+    for (; p < end && *p >= '0' && *p <= '9'; p++) { ex = ex * 10 + (*p - '0'); if (ex > 10000) return false; }
+    e10 += eneg ? -ex : ex;
+  }
+  if (p != end) return false;
+  if (m >> 53) return false;
+  double v = (double)m;
+  if (m == 0) v = 0.0;
+  else if (e10 > 0) { if (e10 > 22) return false; v *= p10[e10]; }
+  else if (e10 < 0) { if (e10 < -22) return false; v /= p10[-e10]; }
+  *out = neg ? -v : v;
+  return true;
+}
+
 // split(str, " \t", double**), gen_func.cpp:390-417: tokens between separators,
 // empty tokens dropped, tokens that strtod does not consume entirely dropped.
 static void split_doubles(char *line, const char *sep, std::vector<double> &out) {
@@ -238,9 +282,13 @@ static void split_doubles(char *line, const char *sep, std::vector<double> &out)
     char *next = s[len] ? s + len + 1 : nullptr;
     s[len] = '\0';
     if (len) {
-      char *end;
-      double v = strtod(s, &end);
-      if (!*end) out.push_back(v);
+      double v;
+      if (fast_strtod(s, len, &v)) out.push_back(v);
+      else {
+        char *end;
+        v = strtod(s, &end);
+        if (!*end) out.push_back(v);
+      }
     }
     s = next;
   }
@@ -298,8 +346,8 @@ static inline bool prep_binary(const Pars &p, bool in_logscale, double *l) {
 }
 
 template <typename F>
-static void parallel_for(unsigned n_threads, uint64_t n, F fn) {
-  if (n_threads <= 1 || n < 4096) { fn(0, n); return; }
+static void parallel_for(unsigned n_threads, uint64_t n, uint64_t min_n, F fn) {
+  if (n_threads <= 1 || n < min_n || n < 2) { fn(0, n); return; }
   std::vector<std::thread> th;
   uint64_t per = (n + n_threads - 1) / n_threads;
   for (unsigned t = 0; t < n_threads; t++) {
@@ -371,7 +419,7 @@ static void load_and_upload(const Pars &p, Engines &eng) {
       const uint64_t n = std::min(chunk, n_sites - s0);
       read_exact(buf.data(), n * n_ind * 24);
       std::atomic<bool> bad{false};
-      parallel_for(p.n_threads, n * n_ind, [&](uint64_t lo, uint64_t hi) {
+      parallel_for(p.n_threads, n * n_ind, 4096, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t e = lo; e < hi; e++)
           if (!prep_binary(p, in_logscale, &buf[3 * e])) bad = true;
       });
@@ -379,59 +427,88 @@ static void load_and_upload(const Pars &p, Engines &eng) {
       eng.upload_sites(buf.data(), s0, n);
     }
   } else {
+    // Text: decompression and line splitting are sequential; tokenising, number parsing and the
+    // per-(individual, site) preparation of a group of lines run on --n_threads threads.  Which lines are
+    // sites (empty line = site at its -INF fill; line without numbers, or a short FIRST line = header) is
+    // settled in file order between the two parallel phases, so errors and messages come in the reference's order.
     const uint64_t n_geno = p.in_probs ? 3 : 1;
-    std::vector<char> line(std::max<size_t>(kLineBuf, n_ind * n_geno * 32 + 4096));
-    std::vector<double> t;
-    uint64_t s = 0, filled = 0, s_base = 0;
-    auto flush = [&]() {
-      if (filled) eng.upload_sites(buf.data(), s_base, filled);
-      s_base += filled;
-      filled = 0;
-    };
+    const uint64_t need = n_ind * n_geno;
+    std::vector<char> line(std::max<size_t>(kLineBuf, need * 32 + 4096));
+    const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(chunk, 1024));
+    std::vector<std::string> lines;
+    std::vector<std::vector<double>> toks(group);
+    std::vector<int64_t> slot(group);  // site slot within the group, or -1
+    uint64_t s = 0;
+    bool eof = false;
     while (s < n_sites) {
-      if (gzgets(fh, line.data(), (int)line.size()) == nullptr) {
+      lines.clear();
+      while (lines.size() < group && lines.size() < n_sites - s + 64) {  // a little read-ahead for header lines
+        if (gzgets(fh, line.data(), (int)line.size()) == nullptr) { eof = true; break; }
+        chomp(line.data());
+        lines.emplace_back(line.data());
+      }
+      if (lines.empty()) {
         if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
         die("read_geno", "cannot read GZip GENO file. Check GENO file and number of sites!");
       }
-      chomp(line.data());
-      double *dst = &buf[filled * n_ind * 3];
-      if (line[0] == '\0') {
-        // empty line: the site keeps its -INF fill (read_data.cpp:21,58-59)
-        for (uint64_t i = 0; i < n_ind; i++) {
-          double *l = dst + 3 * i;
-          l[0] = l[1] = l[2] = -kInf;
-          finish_prep(p, l);
-        }
-      } else {
-        split_doubles(line.data(), " \t", t);
-        if (t.empty() || (s == 0 && t.size() < n_ind * n_geno)) {  // header
-          fprintf(stderr, "> Header found! Skipping line...\n");
-          continue;
-        }
-        if (t.size() < n_ind * n_geno) die("read_geno", "wrong GENO file format. Less fields than expected!");
-        const double *ptr = t.data() + (t.size() - n_ind * n_geno);  // last n_ind*n_geno columns
-        for (uint64_t i = 0; i < n_ind; i++) {
-          double *l = dst + 3 * i;
-          if (p.in_probs) {
-            for (int g = 0; g < 3; g++) l[g] = in_logscale ? ptr[3 * i + g] : log(ptr[3 * i + g]);
-          } else {
-            l[0] = l[1] = l[2] = -kInf;
-            int g = (int)ptr[i];
-            if (g >= 0) {
-              if (g > 2) die("read_geno", "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
-              l[g] = log(1);
-            } else {
-              l[0] = l[1] = l[2] = log((double)1 / 3);
-            }
+      parallel_for(p.n_threads, lines.size(), 1, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; k++)
+          if (lines[k].empty()) toks[k].clear();
+          else split_doubles(&lines[k][0], " \t", toks[k]);
+      });
+      uint64_t filled = 0;
+      for (uint64_t k = 0; k < lines.size(); k++) {
+        slot[k] = -1;
+        if (s + filled == n_sites)  // anything after the last site: the reference stops reading before it
+          die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
+        if (!lines[k].empty()) {
+          if (toks[k].empty() || (s + filled == 0 && toks[k].size() < need)) {  // header
+            fprintf(stderr, "> Header found! Skipping line...\n");
+            continue;
           }
-          post_prob3(l);
-          finish_prep(p, l);
+          if (toks[k].size() < need) die("read_geno", "wrong GENO file format. Less fields than expected!");
         }
+        slot[k] = (int64_t)filled++;
       }
-      s++;
-      if (++filled == chunk) flush();
+      std::atomic<int> bad_geno{0};
+      parallel_for(p.n_threads, lines.size(), 1, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; k++) {
+          if (slot[k] < 0) continue;
+          double *dst = &buf[(uint64_t)slot[k] * n_ind * 3];
+          if (lines[k].empty()) {
+            // empty line: the site keeps its -INF fill (read_data.cpp:21,58-59)
+            for (uint64_t i = 0; i < n_ind; i++) {
+              double *l = dst + 3 * i;
+              l[0] = l[1] = l[2] = -kInf;
+              finish_prep(p, l);
+            }
+            continue;
+          }
+          const double *ptr = toks[k].data() + (toks[k].size() - need);  // last n_ind*n_geno columns
+          for (uint64_t i = 0; i < n_ind; i++) {
+            double *l = dst + 3 * i;
+            if (p.in_probs) {
+              for (int g = 0; g < 3; g++) l[g] = in_logscale ? ptr[3 * i + g] : log(ptr[3 * i + g]);
+            } else {
+              l[0] = l[1] = l[2] = -kInf;
+              int g = (int)ptr[i];
+              if (g >= 0) {
+                if (g > 2) { bad_geno = 1; g = 2; }
+                l[g] = log(1);
+              } else {
+                l[0] = l[1] = l[2] = log((double)1 / 3);
+              }
+            }
+            post_prob3(l);
+            finish_prep(p, l);
+          }
+        }
+      });
+      if (bad_geno) die("read_geno", "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+      if (filled) eng.upload_sites(buf.data(), s, filled);
+      s += filled;
+      if (eof && s < n_sites) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
     }
-    flush();
   }
   char one;
   gzread(fh, &one, 1);

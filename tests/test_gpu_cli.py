@@ -82,6 +82,9 @@ def test_stdin_binary_and_log_scale(tmp_path):
     (["--indep_geno", "--n_boot_rep", "3", "--boot_block_size", "1", "--seed", "99"], dict(n_boot_rep=3, boot_block_size=1, seed=99)),
     (["--n_boot_rep", "2", "--boot_block_size", "16", "--seed", "5", "--evol_model", "2"],
      dict(n_boot_rep=2, boot_block_size=16, seed=5, indep_geno=False, evol_model=2)),
+    # more replicates than one engine batch (32), blocks that leave a tail of sites, per-block partial (sum, cnt)
+    (["--indep_geno", "--pairwise_del", "--n_boot_rep", "40", "--boot_block_size", "12", "--seed", "7", "--n_threads", "3"],
+     dict(n_boot_rep=40, boot_block_size=12, seed=7, pairwise_del=True)),
 ])
 def test_flag_combinations_against_oracle_flow(tmp_path, flags, kw):
     raw = np.fromfile(T_GL, dtype=np.float64)
