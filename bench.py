@@ -142,6 +142,11 @@ def main():
         h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
         cnt_all = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
         cnt_all[0, :] = n_sites
+        dist_all = np.zeros((n_mat, n_pairs))
+        copy_stream = torch.cuda.Stream()
+        step_m = max(1, n_mat // 8)
+        chunks = [(a, min(n_mat, a + step_m)) for a in range(0, n_mat, step_m)]
+        chunk_ev = [torch.cuda.Event() for _ in chunks]
 
     def record_timing():
         t = eng.timing()
@@ -164,15 +169,27 @@ def main():
             if args.backend == "nccl":
                 merge_shards(d_all, None, dst=0)  # ONE RCCL collective for the whole job
                 if rank == 0:
-                    h_all.copy_(d_all, non_blocking=True)
-                    torch.cuda.synchronize()
+                    # results leave the device in chunks of matrices; the host tail (ngd_finish) of one chunk
+                    # runs while the next is in flight
+                    copy_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(copy_stream):
+                        for c, (a, b) in enumerate(chunks):
+                            h_all[a:b].copy_(d_all[a:b], non_blocking=True)
+                            chunk_ev[c].record(copy_stream)
+                    with np.errstate(all="ignore"):
+                        for c, (a, b) in enumerate(chunks):
+                            chunk_ev[c].synchronize()
+                            N.finish(h_all[a:b].numpy().reshape(-1), cnt_all[a:b].reshape(-1), 0, W["evol_model"],
+                                     out=dist_all[a:b].reshape(-1))
+                    last["dist"] = dist_all[-1]
             else:
                 h_all.copy_(d_all)
                 merge_shards(h_all, None, dst=0)
-            if rank == 0:
-                with np.errstate(all="ignore"):
-                    last["dist"] = N.finish(h_all.numpy().reshape(-1), cnt_all.reshape(-1), 0,
-                                            W["evol_model"])[-n_pairs:]
+                if rank == 0:
+                    with np.errstate(all="ignore"):
+                        N.finish(h_all.numpy().reshape(-1), cnt_all.reshape(-1), 0, W["evol_model"],
+                                 out=dist_all.reshape(-1))
+                    last["dist"] = dist_all[-1]
             return
         eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr())
         if record:

@@ -188,12 +188,16 @@ class Engine:
         return int(self._L.ngd_device_bytes(self._h))
 
 
-def finish(sum_, cnt, tot_sites=0, evol_model=1):
-    """Tail of gen_dist(), ngsDist.cpp:372-401, on the host's libm."""
+def finish(sum_, cnt, tot_sites=0, evol_model=1, out=None):
+    """Tail of gen_dist(), ngsDist.cpp:372-401, on the host's libm.  `out` (float64, same size) avoids a fresh
+    allocation per call."""
     L = _lib.load()
     s = np.ascontiguousarray(sum_, dtype=np.float64)
     c = np.ascontiguousarray(cnt, dtype=np.uint64)
-    out = np.empty_like(s)
+    if out is None:
+        out = np.empty_like(s)
+    elif out.dtype != np.float64 or out.size != s.size or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float64 array of the same size")
     _check(L.ngd_finish(s.ctypes.data_as(C.POINTER(C.c_double)), c.ctypes.data_as(C.POINTER(C.c_uint64)),
                         s.size, int(tot_sites), int(evol_model), out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
