@@ -136,3 +136,42 @@ def test_cfg5_bootstrap_replicates_against_the_oracle_on_a_few_pairs():
                     pk = N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)
                     assert c[pk] == co[k] and abs(s[pk] - so[k]) / so[k] < RTOL
                     k += 1
+
+
+def test_cfg5_whole_job_in_one_batch_with_pairwise_deletion():
+    """configs[4] as ONE ngd_run_batch call: the full-data matrix (all-ones multiplicities) + 64 replicates, with
+    5 % missing sites and --pairwise_del so that the per-block count partials carry real information.  Checked:
+    the all-ones row against a plain run (counts exact, sums to rounding), the last replicate against the oracle on
+    a few pairs over all its sites, and the first replicate against a single ngd_run (identical bits)."""
+    n_ind, n_sites, B, R = 500, 500_000, 1000, 64
+    n_blocks = n_sites // B
+    rng_g = N().Taus(12345)
+    maps = np.stack([rng_g.block_map(n_blocks) for _ in range(R)])
+    mult = np.concatenate([np.ones((1, n_blocks), dtype=np.uint32),
+                           np.stack([np.bincount(m.astype(np.int64), minlength=n_blocks) for m in maps]).astype(np.uint32)])
+    idx = [0, 127, 128, 499]
+    sub = np.concatenate([O.synth_indmajor(5, n_ind, n_sites, miss_frac=0.05, i0=i, n_sub=1) for i in idx])
+    with N().Engine(n_ind, n_sites, kernel="mfma", pairwise_del=True) as e:
+        e.synth_fill(5, 0.05)
+        S, Cn = e.run_batch(mult=mult, block_size=B)
+        s0, c0 = e.run()
+        s1, c1 = e.run(maps[0], B)
+    assert np.array_equal(Cn[0], c0) and rel(S[0], s0) < 1e-12
+    assert np.array_equal(Cn[1], c1) and np.array_equal(S[1], s1)
+    so, co = O.all_pairs(sub, pairwise_del=True, site_src=O.boot_site_src(maps[-1], B), n_threads=8)
+    k = 0
+    for a in range(len(idx)):
+        for b in range(a + 1, len(idx)):
+            pk = N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)
+            assert Cn[-1][pk] == co[k] and abs(S[-1][pk] - so[k]) / so[k] < RTOL
+            k += 1
+
+
+def test_many_individuals_against_the_oracle():
+    """n_ind = 3000 (24 x 24 pair tiles, 4.5e6 pairs), few sites: every pair against the oracle."""
+    n_ind, n_sites = 3000, 200
+    p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.1)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=16)
+    with N().Engine(n_ind, n_sites, kernel="mfma", pairwise_del=True) as e:
+        s, c = e.synth_fill(9, 0.1).run()
+    assert np.array_equal(c, co) and rel(s, so) < RTOL
