@@ -270,7 +270,7 @@ def main():
         spot = {"pairs": k, "sites": int(n_eff if src is not None else n_sites), "max_rel_err_vs_oracle": worst}
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 figure
             cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
-            rate_guess = (1.7e8 if W["indep"] else 3.0e5) * cores  # pair-sites/s per thread, measured
+            rate_guess = (1.7e8 if W["indep"] else 2.8e6) * cores  # pair-sites/s per thread, measured
             cs = args.cpu_sites or int(max(64, min(n_sites, 15.0 * rate_guess / n_pairs)))
             pc = O.synth_indmajor(W["seed"], n_ind, cs)
             tc = time.perf_counter()
