@@ -3,13 +3,21 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--kernel ...]
 
-One "step" = one replicate of the hot path over the whole resident data set:
-accumulation kernel(s) -> deterministic slab reduction -> (N>1: RCCL reduce of
-the disjoint shards to rank 0) -> copy to host -> /cnt and evolutionary-model
-transform with the host's libm (the tail of gen_dist, ngsDist.cpp:372-401).
+One "step" = one job of the hot path over the resident data set: accumulation
+kernel(s) -> deterministic slab reduction -> copy to host -> /cnt and
+evolutionary-model transform with the host's libm (the tail of gen_dist,
+ngsDist.cpp:372-401), with ONE collective per job when N > 1.
 Inputs are synthetic (counter-based generator), generated ON the GPU
-before the timed region, replicated per rank; pair tiles are dealt over ranks
-(strong scaling: the matrix is fixed as N grows).
+before the timed region.
+
+N > 1 (--shard):
+  replicates (default for the single-matrix workloads; weak scaling): matrices are independent units
+      (ngsDist.cpp:217-289), so every GPU holds the data set and computes ONE matrix of the job -- rank 0 the
+      full-data matrix, rank r the r-th bootstrap replicate at the reference's default --boot_block_size 1,
+      drawn from its taus stream -- and one RCCL all-gather brings the N finished matrices together;
+  sites (default for cfg5; strong scaling): each GPU holds 1/N of the sites of all individuals, computes every
+      pair over its range, partial sums are added by one RCCL reduce;
+  pairs (strong scaling): pair tiles dealt over GPUs, input replicated, disjoint results.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
 `roofline` for the dominant kernel from HIP-event timings taken inside this run,
@@ -53,9 +61,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
-    ap.add_argument("--shard", default="sites", choices=["sites", "pairs"],
-                    help="N>1: split the site axis (each rank holds 1/N of the data, all pairs; sums are added) "
-                         "or deal pair tiles over ranks (input replicated; disjoint results)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "replicates", "sites", "pairs"],
+                    help="N>1: one matrix (bootstrap replicate) per GPU, or split the site axis (each rank holds 1/N "
+                         "of the data, all pairs; sums are added), or deal pair tiles over ranks (input replicated; "
+                         "disjoint results); auto = replicates for single-matrix workloads, sites for cfg5")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,10 +102,21 @@ def main():
     if kernel == "auto":
         kernel = "mfma" if W["indep"] else "em_fast"
 
+    shard = args.shard
+    if shard == "auto":
+        shard = "replicates" if W["n_boot"] == 0 else "sites"
+    if world == 1:
+        shard = "none"
+    by_sites, by_reps = shard == "sites", shard == "replicates"
+    if by_reps:
+        if W["n_boot"]:
+            raise SystemExit("bench.py: --shard replicates is for the single-matrix workloads (cfg5: use sites)")
+        # one matrix per GPU: the full-data matrix + (N-1) bootstrap replicates at the reference's default block size
+        W["n_boot"], W["block"] = world - 1, 1
+
     # bootstrap geometry of the WHOLE data set
     n_mat = W["n_boot"] + 1
     n_eff = n_sites - n_sites % W["block"]
-    by_sites = world > 1 and args.shard == "sites"
     if by_sites:
         # contiguous site ranges, whole bootstrap blocks and whole 16-site groups per rank
         unit = int(np.lcm(16, W["block"]))
@@ -109,7 +129,7 @@ def main():
     else:
         lo, hi = 0, n_sites
         eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank,
-                       shard_rank=rank, shard_world=world)
+                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world)
         eng.synth_fill(W["seed"], 0.0)
 
     d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
@@ -131,7 +151,14 @@ def main():
     # Bootstrap workloads: all replicates of the job go to the engine in ONE call (ngd_run_mult_batch: per-block
     # partial sums once, then every replicate is a weighted reduction of them).  When the blocks cover the
     # whole data set the full-data matrix is the all-ones row of the same batch, otherwise it is its own pass.
-    batched = W["n_boot"] > 0
+    batched = W["n_boot"] > 0 and not by_reps
+    if by_reps:
+        d_dist = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
+        h_dist = torch.empty(n_pairs, dtype=torch.float64).pin_memory()
+        d_all = torch.zeros((n_mat, n_pairs), dtype=torch.float64, device=dev)
+        h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
+        cnt_mine = np.full(n_pairs, n_sites if rank == 0 else n_eff, dtype=np.uint64)
+        rows_dev, rows_host = list(d_all.unbind(0)), list(h_all.unbind(0))
     if batched:
         n_blocks = n_eff // W["block"]
         fold0 = n_eff == n_sites
@@ -156,6 +183,28 @@ def main():
 
     def step(record):
         eng.drop_caches()  # bootstrap block partial sums are recomputed in every step (no carried work)
+        if by_reps:
+            # this rank's matrix, start to finish; then ONE collective puts the N finished matrices together
+            eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rank], W["block"])
+            if record:
+                record_timing()
+            if args.backend == "nccl":
+                h_sum.copy_(d_sum, non_blocking=True)
+                torch.cuda.synchronize()
+            else:
+                h_sum.copy_(d_sum)
+            with np.errstate(all="ignore"):
+                N.finish(h_sum.numpy(), cnt_mine, 0, W["evol_model"], out=h_dist.numpy())
+            if args.backend == "nccl":
+                d_dist.copy_(h_dist, non_blocking=True)
+                dist.all_gather(rows_dev, d_dist)
+                if rank == 0:
+                    h_all.copy_(d_all, non_blocking=True)
+                    torch.cuda.synchronize()
+            else:
+                dist.all_gather(rows_host, h_dist)
+            last["dist"] = h_all[-1].numpy()
+            return
         if batched:
             first = 0 if fold0 else 1
             if not fold0:
@@ -219,7 +268,12 @@ def main():
         return float(t.item())
 
     if world > 1:  # communicator and buffers come up outside the timed region whatever --warmup is
-        if args.backend == "nccl":
+        if by_reps:
+            if args.backend == "nccl":
+                dist.all_gather(rows_dev, d_dist)
+            else:
+                dist.all_gather(rows_host, h_dist)
+        elif args.backend == "nccl":
             merge_shards(d_all if batched else d_sum, None, dst=0)
         else:
             merge_shards(h_all if batched else h_sum, None, dst=0)
@@ -281,6 +335,23 @@ def main():
                    "pair_sites_per_s": cpu_ps, "seconds": tc,
                    "sample": "first %d of %d sites, all %d pairs, same generator/seed; rate scaled linearly "
                              "in n_sites to one full matrix" % (cs, n_sites, n_pairs)}
+            if not W["indep"]:
+                # the reference's OWN em2() (oracle/_ref/libref_em2.so = emOptim2.cpp compiled as it lies), one
+                # thread, on pair-sites of this workload: the per-(pair, site) cost of the reference's EM branch
+                try:
+                    R = O.ref_lib()
+                    m = 1_000_000
+                    pa = np.ascontiguousarray(O.synth_indmajor(W["seed"], n_ind, m, i0=0, n_sub=1)[0])
+                    pb = np.ascontiguousarray(O.synth_indmajor(W["seed"], n_ind, m, i0=1, n_sub=1)[0])
+                    sfs = np.empty((m, 9))
+                    tr = time.perf_counter()
+                    R.ref_em2_batch(m, O._dp(pa), O._dp(pb), O._dp(sfs))
+                    tr = time.perf_counter() - tr
+                    cpu["reference_em2"] = {"pair_sites_per_s": m / tr, "cores": 1, "kind": "reference",
+                                            "sample": "em2() of the reference's emOptim2.cpp on the first %d sites of "
+                                                      "pair (0,1); excludes gen_dist's loop around it" % m}
+                except Exception as exc:
+                    cpu["reference_em2"] = {"error": repr(exc)}
     except Exception as exc:  # the oracle is a checker; never let it take the bench line down
         cpu = {"error": repr(exc)}
 
@@ -319,7 +390,8 @@ def main():
     out = {
         "metric": "pair-distances/sec", "value": value, "unit": "pair-distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": "weak" if by_reps or (world == 1 and not W["n_boot"] and args.shard in ("auto", "replicates")) else "strong", "vs_baseline": None,
+        "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: n_ind=%d n_sites=%d %s evol_model=%d n_boot_rep=%d boot_block_size=%d"
                                % (args.workload, n_ind, n_sites, "--indep_geno" if W["indep"] else "EM",
@@ -328,6 +400,9 @@ def main():
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs), sums added by "
                                 "one RCCL reduce" % (world, world)) if by_sites else
+                               ("one matrix per GPU (full data + %d bootstrap replicates, block size 1), data set "
+                                "resident on every GPU, one RCCL all-gather of the finished matrices" % (world - 1))
+                               if by_reps else
                                ("pair tiles dealt over %d rank(s), input replicated" % world)},
         "roofline": roof, "cpu_baseline": cpu, "spot_check": spot,
         "device_bytes": eng.device_bytes(),
