@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const 
 template <bool WEIGHTED, int DEPTH, int WPS, bool EXACT>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
-    const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
+    const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   // slice end stays in bounds and is never consumed (it is drained before the
   // epilogue, because the compiler is free to re-use those registers there).
   constexpr int LPF = WM + WN + (WEIGHTED ? 1 : 0);  // loads per fetch
+  // WEIGHTED (one bootstrap replicate): the slice is a range of the LIST of k-groups that have a non-zero
+  // weight (layout.hip); kidx() maps a list position to the k-group, a scalar load issued one trip ahead of
+  // the fetch that needs it.  Every job of a slice walks the same list, so the slice still moves as one.
+  auto kidx = [&](uint64_t pos) -> uint64_t { return WEIGHTED ? (uint64_t)kgl[pos] : pos; };
   auto fetch = [&](int d, uint64_t kg) {
     const double *xa = pa + kg * kstride;
     const double *xb = pb + kg * kstride;
@@ -142,8 +146,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   auto run = [&](auto rows_c, auto cols_c, auto tri_c) {
     constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value;
     constexpr bool TRI = decltype(tri_c)::value;
+    uint64_t nxt[DEPTH];  // the k-group the next refill of buffer d fetches
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) fetch(d, kg0 + d);
+    for (int d = 0; d < DEPTH; d++) fetch(d, kidx(kg0 + d));
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) nxt[d] = kidx(kg0 + d + DEPTH);
     for (uint64_t kg = kg0; kg < kg1; kg += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
@@ -162,8 +169,9 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
-        fetch(d, kg + d + DEPTH);
+        fetch(d, nxt[d]);
         __builtin_amdgcn_sched_barrier(0);
+        nxt[d] = kidx(kg + d + 2 * DEPTH);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
@@ -201,8 +209,11 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
       for (int n = 0; n < PN; n++) asm volatile("" : "+v"(bq[d][n]));
       if (WEIGHTED) asm volatile("" : "+v"(wq[d]));
     };
+    uint64_t nxt[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) fetch_x(d, kg0 + d);
+    for (int d = 0; d < D; d++) fetch_x(d, kidx(kg0 + d));
+#pragma unroll
+    for (int d = 0; d < D; d++) nxt[d] = kidx(kg0 + d + D);
     for (uint64_t kg = kg0; kg < kg1; kg += D) {
 #pragma unroll
       for (int d = 0; d < D; d++) {
@@ -221,8 +232,9 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        fetch_x(d, kg + d + D);
+        fetch_x(d, nxt[d]);
         __builtin_amdgcn_sched_barrier(0);
+        nxt[d] = kidx(kg + d + 2 * D);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -270,8 +282,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 }  // namespace
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const double *d_ws /* wk */, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
-                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
+                           const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
+                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
   if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)
   static const int variant = [] {
@@ -281,7 +293,7 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
   // EXACT: one job per (single-wavefront) workgroup -- jobs of different shapes last differently, and a
   // wavefront that is done should not wait for three siblings before its slot is handed on
 #define NGD_MFMA(W, D, P, X)                                                                                    \
-  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_jobs, \
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
                      n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
   // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
   // (profiles/r01_*): the third wavefront covers the others' load phases.

@@ -43,6 +43,9 @@ struct ngd_engine {
   // bootstrap
   uint32_t *d_mult = nullptr, *d_ws = nullptr;
   double *d_wk = nullptr;  // multiplicity per contraction index k, as a double (MFMA kernel)
+  uint32_t *d_kgl = nullptr, *d_kgcnt = nullptr;  // k-groups a replicate visits (list + compaction scratch)
+  uint32_t *h_mult = nullptr;                      // pinned: multiplicities counted from block maps
+  uint64_t cap_h_mult = 0;
   uint64_t cap_blocks = 0;
   // shard
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
@@ -133,7 +136,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk,
+  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt};
   for (void *p : ptrs)
@@ -144,6 +147,7 @@ void ngd_destroy(ngd_engine *e) {
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
   }
   if (e->d_nan) hipFree(e->d_nan);
+  if (e->h_mult) hipHostFree(e->h_mult);
   for (auto &v : e->ev)
     if (v) hipEventDestroy(v);
   if (e->st) hipStreamDestroy(e->st);
@@ -492,16 +496,18 @@ int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_
 
 int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) { return ngd_synth_fill_range(e, seed, miss_frac, 0); }
 
-static void launch_accumulate(ngd_engine *e, const uint32_t *w, uint64_t sites_eff, uint32_t n_ks, uint64_t per_slice,
-                              uint64_t kg_lim, double *slab) {
+// w != NULL: one bootstrap replicate; for the MFMA kernel kgl is then the list of k-groups to visit and
+// per_slice / kg_lim count list entries
+static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *kgl, uint64_t sites_eff, uint32_t n_ks,
+                              uint64_t per_slice, uint64_t kg_lim, double *slab) {
   const ngd_geom &g = e->g;
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
       if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
         ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
       else
-        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, e->d_jobs, e->n_wg, e->exact_shapes,
-                              n_ks, per_slice, kg_lim, slab);
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, w ? kgl : nullptr, e->d_jobs, e->n_wg,
+                              e->exact_shapes, n_ks, per_slice, kg_lim, slab);
       break;
     default:
       ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -531,6 +537,8 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   uint64_t n_eff = g.n_sites;
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
+  uint32_t n_list = 0;
+  const bool list_pass = mult && e->kernel == NGD_KERNEL_MFMA && env_u64("NGD_MFMA_VARIANT", 0) < 2;
   HIPCHK(hipEventRecord(e->ev[0], e->st));
   if (mult) {
     n_eff = n_blocks * block_size;
@@ -544,7 +552,19 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
     }
     HIPCHK(hipMemcpyAsync(e->d_mult, mult, n_blocks * 4, hipMemcpyHostToDevice, e->st));
     ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws, e->d_wk);
-    HIPCHK(hipStreamSynchronize(e->st));  // `mult` is pageable host memory
+    if (list_pass) {  // the k-groups this replicate visits at all (about 1/e of the sites are not drawn)
+      const uint32_t nb = ngd_kg_count_blocks(g.n_kg);
+      if (!e->d_kgl) {
+        int rc = dev_alloc(e, &e->d_kgl, g.n_kg + NGD_KG_LIST_PAD, false);
+        if (rc) return rc;
+        rc = dev_alloc(e, &e->d_kgcnt, (uint64_t)nb + 1, false);
+        if (rc) return rc;
+      }
+      ngd_launch_kg_compact(e->st, e->d_wk, g.n_kg, (uint32_t)g.n_kg, e->d_kgcnt, e->d_kgl);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&n_list, e->d_kgcnt + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    }
+    HIPCHK(hipStreamSynchronize(e->st));  // `mult` is pageable host memory; n_list has arrived
     ws = e->d_ws;
   }
   HIPCHK(hipMemsetAsync(d_sum, 0, n_pairs * sizeof(double), e->st));
@@ -553,8 +573,11 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   if (e->kernel == NGD_KERNEL_STREAM)
     ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
                             e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
+  else if (list_pass)  // slices are equal shares of the list (whole multiples of 4 entries: the deepest operand ring)
+    launch_accumulate(e, ws, e->d_kgl, n_eff, e->n_ks, (((uint64_t)n_list + e->n_ks - 1) / e->n_ks + 3) / 4 * 4, n_list,
+                      e->slab);
   else
-    launch_accumulate(e, ws, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
+    launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[2], e->st));
   if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
@@ -630,7 +653,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     e->boot_nks = (uint32_t)nks;
     e->boot_sub = (uint32_t)sub;
     e->boot_per_slice = unit / sub;
-    launch_accumulate(e, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
+    launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
     HIPCHK(hipGetLastError());
     e->boot_B = block_size;
     e->boot_blocks = n_blocks;
@@ -702,14 +725,19 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   if (n_blocks > g.n_sites / block_size) return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
   const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
   const uint64_t n_eff = n_blocks * block_size;
-  std::vector<uint32_t> counted;
   std::vector<unsigned long long> drawn(n_rep, 0);  // sites visited, with multiplicity = gen_dist's cnt
   std::vector<uint32_t> mult_max(n_rep, 0);
   const uint32_t *mult = mult_in;
   if (block_maps) {
-    counted.assign((uint64_t)n_rep * n_blocks, 0);
+    const uint64_t need = (uint64_t)n_rep * n_blocks;
+    if (need > e->cap_h_mult) {  // pinned and kept: a replicate at block size 1 counts a million draws per call
+      if (e->h_mult) { HIPCHK(hipHostFree(e->h_mult)); e->h_mult = nullptr; e->cap_h_mult = 0; }
+      HIPCHK(hipHostMalloc((void **)&e->h_mult, need * sizeof(uint32_t), hipHostMallocDefault));
+      e->cap_h_mult = need;
+    }
+    memset(e->h_mult, 0, need * sizeof(uint32_t));
     for (uint32_t r = 0; r < n_rep; r++) {
-      uint32_t *m = &counted[(uint64_t)r * n_blocks];
+      uint32_t *m = e->h_mult + (uint64_t)r * n_blocks;
       const uint64_t *bm = block_maps + (uint64_t)r * n_blocks;
       for (uint64_t b = 0; b < n_blocks; b++) {
         if (bm[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
@@ -717,7 +745,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
       }
       drawn[r] = n_eff;
     }
-    mult = counted.data();
+    mult = e->h_mult;
   } else {
     for (uint32_t r = 0; r < n_rep; r++)
       for (uint64_t b = 0; b < n_blocks; b++) {

@@ -161,7 +161,101 @@ __global__ void k_planes(const uint32_t *__restrict__ ws, uint64_t n_sites, uint
   }
 }
 
+// ---- list of the k-groups a bootstrap replicate visits at all -------------------------------------
+// A k-group (4 consecutive contraction indices = parts of two sites) whose four weights are zero
+// contributes nothing: about 1/e of the sites of a replicate are not drawn (1/e^2 of the k-groups at
+// block size 1, 1/e of them for blocks of a few sites and more).  The weighted MFMA pass walks this list
+// instead of the whole k range.  Order-preserving compaction in three small kernels (count per 1024
+// k-groups, scan of the counts, scatter), so the list is ascending and the pass stays deterministic.
+constexpr int CPT = 4;               // k-groups per thread
+constexpr int CPB = 256 * CPT;       // k-groups per workgroup
+
+__device__ __forceinline__ bool kg_live(const double *__restrict__ wk, uint64_t kg, uint64_t n_kg) {
+  if (kg >= n_kg) return false;
+  const double *w = wk + 4 * kg;
+  return w[0] != 0.0 || w[1] != 0.0 || w[2] != 0.0 || w[3] != 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_kg_count(const double *__restrict__ wk, uint64_t n_kg, uint32_t *counts) {
+  const uint64_t base = (uint64_t)blockIdx.x * CPB + threadIdx.x * CPT;
+  int c = 0;
+#pragma unroll
+  for (int t = 0; t < CPT; t++) c += kg_live(wk, base + t, n_kg);
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = sh[0];
+}
+
+// exclusive scan of the per-workgroup counts, in place; the grand total goes to counts[n]
+__global__ __launch_bounds__(1024) void k_kg_scan(uint32_t *counts, uint32_t n) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < n ? counts[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+      const uint32_t add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n) counts[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_kg_scatter(const double *__restrict__ wk, uint64_t n_kg,
+                                                     const uint32_t *__restrict__ offsets, uint32_t *list) {
+  const uint64_t base = (uint64_t)blockIdx.x * CPB + threadIdx.x * CPT;
+  bool live[CPT];
+  uint32_t c = 0;
+#pragma unroll
+  for (int t = 0; t < CPT; t++) { live[t] = kg_live(wk, base + t, n_kg); c += live[t]; }
+  __shared__ uint32_t sh[256];
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t o = offsets[blockIdx.x] + sh[threadIdx.x] - c;
+#pragma unroll
+  for (int t = 0; t < CPT; t++)
+    if (live[t]) list[o++] = (uint32_t)(base + t);
+}
+
+// the entries past the end of the list point at the zeroed tail k-groups of the images (pipeline run-ahead)
+__global__ void k_kg_pad(uint32_t *list, const uint32_t *total, uint32_t n_pad_entries, uint32_t tail_kg) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_pad_entries) list[*total + t] = tail_kg;
+}
+
 }  // namespace
+
+uint32_t ngd_kg_count_blocks(uint64_t n_kg) { return (uint32_t)((n_kg + CPB - 1) / CPB); }
+
+void ngd_launch_kg_compact(hipStream_t st, const double *d_wk, uint64_t n_kg, uint32_t tail_kg, uint32_t *d_counts,
+                           uint32_t *d_list) {
+  const uint32_t nb = ngd_kg_count_blocks(n_kg);
+  hipLaunchKernelGGL(k_kg_count, dim3(nb), dim3(256), 0, st, d_wk, n_kg, d_counts);
+  hipLaunchKernelGGL(k_kg_scan, dim3(1), dim3(1024), 0, st, d_counts, nb);
+  hipLaunchKernelGGL(k_kg_scatter, dim3(nb), dim3(256), 0, st, d_wk, n_kg, d_counts, d_list);
+  hipLaunchKernelGGL(k_kg_pad, dim3(1), dim3(64), 0, st, d_list, d_counts + nb, (uint32_t)NGD_KG_LIST_PAD, tail_kg);
+}
 
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
                        uint64_t s0, uint64_t n_chunk, const ngd_score &score, int pairwise_del,

@@ -9,6 +9,7 @@
 #define NGD_IG 16        // individuals per fragment group (one MFMA operand edge)
 #define NGD_IG_PER_TILE (NGD_TILE / NGD_IG)
 #define NGD_KG_TAIL 8    // zeroed k-groups appended to the operand images (pipeline run-ahead)
+#define NGD_KG_LIST_PAD 16  // entries appended to a k-group list, all pointing at the first tail k-group
 
 typedef double ngd_d4 __attribute__((ext_vector_type(4)));
 
@@ -79,6 +80,11 @@ void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double m
                       unsigned long long *mask);
 void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
                         const uint32_t *d_mult, uint32_t *d_ws, double *d_wk);
+// list of the k-groups with a non-zero bootstrap weight (ascending), NGD_KG_LIST_PAD entries of padding;
+// d_counts: ngd_kg_count_blocks(n_kg) + 1 words of scratch, the last one receives the list length
+uint32_t ngd_kg_count_blocks(uint64_t n_kg);
+void ngd_launch_kg_compact(hipStream_t st, const double *d_wk, uint64_t n_kg, uint32_t tail_kg, uint32_t *d_counts,
+                           uint32_t *d_list);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 
@@ -88,9 +94,11 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
                              const uint64_t *d_pairs, uint64_t n_owned, double *d_sum);
 
 // accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
+// d_wk / d_kgl: bootstrap weights per contraction index and the list of k-groups to visit (both or neither);
+// with a list, kg_per_slice and n_kg_eff count LIST entries
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                           const double *d_wk, const ngd_job *d_jobs, uint32_t n_wg, int exact_shapes,
-                           uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
+                           const double *d_wk, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
+                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
 
 // accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
 void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
