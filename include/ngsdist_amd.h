@@ -173,7 +173,8 @@ int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
  * (sum, cnt) once and forms up to 32 replicates per pass over them, so a batch costs little more than
  * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run().
  * When the partials do not apply (streaming kernel, MFMA kernel with block_size % 4 != 0, not enough
- * device memory) this is n_rep weighted accumulation passes. */
+ * device memory) this is n_rep weighted accumulation passes on the --indep_geno path (each walks only the
+ * sites its replicate drew) and one pass per 16 replicates on the EM path. */
 int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                   uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
@@ -182,6 +183,21 @@ int ngd_run_mult_batch(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint
                        uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_mult_batch_device(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks,
                               uint64_t block_size, void *d_sum, void *d_cnt);
+
+/* The WHOLE replicate loop ngsDist.cpp:217-289 in one call: matrix 0 is the full data set (what
+ * ngd_run(e, NULL, ...) returns), matrices 1..n_rep the bootstrap replicates of block_maps
+ * ([n_rep][n_blocks], drawn as for ngd_run_batch).  Outputs are [n_rep + 1][n_pairs].  Knowing the whole
+ * job lets the engine share work between the matrices: when the blocks cover every site the full-data
+ * matrix is the all-ones combination of the same per-block partials as the replicates; on the EM path
+ * (no --indep_geno) with blocks too small for partials -- e.g. the default --boot_block_size 1 -- up to 16
+ * matrices, the full-data one included, share ONE pass of the per-site EM, which does not depend on the
+ * replicate.  Replicates carry the same bits as from ngd_run(); matrix 0 agrees with ngd_run(e, NULL) to
+ * rounding (exactly for called genotypes) because its sum may be formed in a different order.
+ * n_rep = 0 is ngd_run(e, NULL, ...). */
+int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                uint64_t block_size, double *sum, uint64_t *cnt);
+int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                       uint64_t block_size, void *d_sum, void *d_cnt);
 
 /* Bootstrap replicates re-use per-block partial (sum, cnt) computed on the first
  * run that carries a block map (valid for that block size / block count;

@@ -164,7 +164,80 @@ __global__ __launch_bounds__(256) void k_accum_em(const double *__restrict__ PA,
   slab[((uint64_t)ks * n_pad + i) * n_pad + j] = acc;
 }
 
+// RB bootstrap replicates in ONE pass: the EM of a (pair, site) does not depend on the replicate, only
+// its weight does, so the site's contribution c is computed once and added RB times,
+//   acc[r] = acc[r] + c * W[s][r]          (the arithmetic of the one-replicate kernel: same bits),
+// W site-major so that the RB weights of a site are one scalar load.  The slab holds RB planes per slice.
+template <bool FAST, bool PDEL, int RB>
+__global__ __launch_bounds__(256) void k_accum_em_batch(const double *__restrict__ PA, const double *__restrict__ Wb,
+                                                         ngd_score sc, const ngd_tile *__restrict__ tiles,
+                                                         uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad,
+                                                         uint64_t n_ind, uint64_t n_sites_eff,
+                                                         uint64_t sites_per_slice, double *__restrict__ slab) {
+  const uint32_t tile = blockIdx.x % n_tiles;
+  const uint32_t ks = blockIdx.x / n_tiles;
+  const uint32_t ig = tiles[tile].ti, jg = tiles[tile].tj;
+  const uint32_t i = ig * 16 + (threadIdx.x >> 4);
+  const uint32_t j = jg * 16 + (threadIdx.x & 15);
+  const bool valid = i < j && j < n_ind;
+  const uint64_t s0 = (uint64_t)ks * sites_per_slice;
+  uint64_t s1 = s0 + sites_per_slice;
+  if (s1 > n_sites_eff) s1 = n_sites_eff;
+  const uint64_t kstride = (uint64_t)n_ig * 64;
+  double acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; r++) acc[r] = 0;
+  if (valid) {
+    const double *pi = PA + (uint64_t)ig * 64 + (i & 15);
+    const double *pj = PA + (uint64_t)jg * 64 + (j & 15);
+    for (uint64_t s = s0; s < s1; s++) {
+      const double *w = Wb + s * RB;  // uniform across the workgroup
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < RB; r++) any |= w[r] != 0.0;
+      if (!any) continue;  // drawn by none of these replicates
+      double g1[3], g2[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const uint64_t k = 3 * s + c;
+        const uint64_t off = (k >> 2) * kstride + (k & 3) * 16;
+        g1[c] = pi[off];
+        g2[c] = pj[off];
+      }
+      if (PDEL && (ngd_miss(g1[0], g1[1], g1[2]) || ngd_miss(g2[0], g2[1], g2[2]))) continue;
+      // the site's score-weighted sum, exactly as the one-replicate kernel forms it (0 + c * 1 == c)
+      const double c = FAST ? site_fast(g1, g2, sc, 0.0, 1.0) : site_faithful(g1, g2, sc, 0.0, 1.0, true);
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] = acc[r] + c * w[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; r++) slab[(((uint64_t)ks * RB + r) * n_pad + i) * n_pad + j] = acc[r];
+}
+
 }  // namespace
+
+void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
+                               uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,
+                               const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
+                               uint64_t sites_per_slice, double *slab) {
+  if (!n_tiles16) return;
+  dim3 grid(n_tiles16 * n_ks), block(256);
+#define NGD_EMB(F, P, R)                                                                                   \
+  hipLaunchKernelGGL((k_accum_em_batch<F, P, R>), grid, block, 0, st, PA, d_Wb, score, d_tiles16, n_tiles16, \
+                     g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab)
+#define NGD_EMB_R(F, P)                                    \
+  do {                                                     \
+    if (rb == 4) NGD_EMB(F, P, 4);                         \
+    else if (rb == 8) NGD_EMB(F, P, 8);                    \
+    else NGD_EMB(F, P, 16);                                \
+  } while (0)
+  const bool p = pairwise_del != 0;
+  if (fast) { if (p) NGD_EMB_R(true, true); else NGD_EMB_R(true, false); }
+  else      { if (p) NGD_EMB_R(false, true); else NGD_EMB_R(false, false); }
+#undef NGD_EMB_R
+#undef NGD_EMB
+}
 
 void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                          uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,

@@ -580,7 +580,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
     launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[2], e->st));
-  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, e->d_tiles, e->n_tiles, d_sum);
+  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, d_sum);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
@@ -711,9 +711,76 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   return NGD_OK;
 }
 
-// n_rep == 0: the full data set (rep 0).  Else n_rep bootstrap replicates, given as block maps
-// (multiplicities are counted from them) or directly as multiplicities; outputs are [n_rep][n_pairs].
-static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *mult_in, uint32_t n_rep,
+// EM path when the blocks are too many for per-block partials (e.g. the reference's default block size 1):
+// the EM of a (pair, site) does not depend on the replicate, so up to 16 replicates share ONE accumulation pass
+// (accum_em.hip k_accum_em_batch) -- and, with lead_full, so does the full-data matrix, as the row whose weight
+// is 1 on every site.  Outputs: [lead_full + n_rep][n_pairs]; a replicate's bits equal the one-replicate pass's.
+static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mult_max, const unsigned long long *drawn,
+                         uint32_t n_rep, bool lead_full, uint64_t n_blocks, uint64_t block_size, double *d_sum,
+                         unsigned long long *d_cnt, bool add_timing) {
+  const ngd_geom &g = e->g;
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind), plane = (uint64_t)g.n_pad * g.n_pad;
+  const uint64_t n_eff = n_blocks * block_size;
+  const uint32_t n_mat = n_rep + (lead_full ? 1u : 0u);
+  const bool fast = e->kernel == NGD_KERNEL_EM_FAST;
+  HIPCHK(hipMemsetAsync(d_sum, 0, (uint64_t)n_mat * n_pairs * sizeof(double), e->st));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_mat * n_pairs * sizeof(unsigned long long), e->st));
+  e->boot_B = 0;  // the partial-sum slab is re-used as this pass's scratch
+  for (uint32_t c0 = 0; c0 < n_mat; c0 += 16) {
+    const uint32_t nr = std::min(16u, n_mat - c0);
+    const int rb = nr <= 4 ? 4 : nr <= 8 ? 8 : 16;
+    const bool lead = lead_full && c0 == 0;
+    const uint32_t q0 = c0 - ((lead_full && c0 > 0) ? 1u : 0u);  // first replicate of the chunk
+    const uint32_t nq = nr - (lead ? 1u : 0u);                     // replicates in the chunk
+    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (uint64_t)e->n_ks * rb * plane);
+    if (rc) return rc;
+    rc = ensure_cap(e, &e->d_W, &e->cap_W, g.n_sites * (uint64_t)rb);
+    if (rc) return rc;
+    rc = ensure_cap(e, &e->d_M, &e->cap_M, std::max<uint64_t>(1, (uint64_t)nq * n_blocks));
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev[0], e->st));
+    if (nq) HIPCHK(hipMemcpyAsync(e->d_M, mult + (uint64_t)q0 * n_blocks, (uint64_t)nq * n_blocks * 4, hipMemcpyHostToDevice, e->st));
+    ngd_launch_weights_batch(e->st, e->d_M, nq, (uint32_t)rb, lead ? 1 : 0, n_blocks, block_size, g.n_sites, g.n_sites,
+                             e->d_W);
+    HIPCHK(hipEventRecord(e->ev[1], e->st));
+    ngd_launch_accum_em_batch(e->st, g, e->PA, e->d_W, rb, lead ? g.n_sites : n_eff, e->sc, e->cfg.pairwise_del, fast,
+                              e->d_tiles16, e->n_tiles16, e->n_ks, e->per_slice, e->slab_boot);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[2], e->st));
+    for (uint32_t r = 0; r < nr; r++)
+      ngd_launch_reduce(e->st, g, e->slab_boot + (uint64_t)r * plane, e->n_ks, (uint32_t)rb, e->d_tiles, e->n_tiles,
+                        d_sum + (uint64_t)(c0 + r) * n_pairs);
+    HIPCHK(hipEventRecord(e->ev[3], e->st));
+    for (uint32_t r = 0; r < nr; r++) {
+      unsigned long long *cnt_r = d_cnt + (uint64_t)(c0 + r) * n_pairs;
+      const bool is_lead = lead && r == 0;
+      const uint32_t q = q0 + r - (lead ? 1u : 0u);
+      if (!e->cfg.pairwise_del) {
+        ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[q], nullptr, 1, cnt_r);
+      } else if (is_lead) {
+        ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles16, e->n_tiles16, cnt_r);
+      } else {
+        uint32_t n_planes = 0;
+        while (n_planes < 32 && (mult_max[q] >> n_planes)) n_planes++;
+        ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)(q - q0) * n_blocks, e->d_ws,
+                           nullptr);
+        ngd_launch_planes(e->st, e->d_ws, g.n_sites, g.n_words, n_planes, e->planes);
+        ngd_launch_count(e->st, g, e->mask, e->planes, n_planes, e->d_tiles16, e->n_tiles16, cnt_r);
+      }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[4], e->st));
+    HIPCHK(hipStreamSynchronize(e->st));
+    read_timing(e, lead ? g.n_sites : n_eff, 1, add_timing || c0 > 0);
+  }
+  return NGD_OK;
+}
+
+// The replicate loop: optionally the full data set (matrix 0, lead_full), then n_rep bootstrap replicates given
+// as block maps (multiplicities are counted from them) or directly as multiplicities.  Outputs are
+// [lead_full + n_rep][n_pairs].  The plan is the cheapest that applies: per-block partials (one pass, then a
+// weighted reduction per batch of replicates), the EM batch pass, or one (weighted) pass per matrix.
+static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *mult_in, uint32_t n_rep, bool lead_full,
                     uint64_t n_blocks, uint64_t block_size, double *d_sum, unsigned long long *d_cnt) {
   if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
   if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
@@ -725,41 +792,84 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   if (n_blocks > g.n_sites / block_size) return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
   const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
   const uint64_t n_eff = n_blocks * block_size;
-  std::vector<unsigned long long> drawn(n_rep, 0);  // sites visited, with multiplicity = gen_dist's cnt
-  std::vector<uint32_t> mult_max(n_rep, 0);
-  const uint32_t *mult = mult_in;
-  if (block_maps) {
-    const uint64_t need = (uint64_t)n_rep * n_blocks;
+  const uint32_t lead = lead_full ? 1u : 0u;
+  std::vector<unsigned long long> drawn(n_rep + lead, 0);  // sites visited, with multiplicity = gen_dist's cnt
+  std::vector<uint32_t> mult_max(n_rep + lead, 0);
+  // multiplicities of matrices lead..: counted into (or copied behind) a leading all-ones row, which stands for
+  // the full data set when the blocks cover every site
+  const uint64_t need = (uint64_t)(n_rep + lead) * n_blocks;
+  if (block_maps || lead) {
     if (need > e->cap_h_mult) {  // pinned and kept: a replicate at block size 1 counts a million draws per call
       if (e->h_mult) { HIPCHK(hipHostFree(e->h_mult)); e->h_mult = nullptr; e->cap_h_mult = 0; }
       HIPCHK(hipHostMalloc((void **)&e->h_mult, need * sizeof(uint32_t), hipHostMallocDefault));
       e->cap_h_mult = need;
     }
-    memset(e->h_mult, 0, need * sizeof(uint32_t));
+  }
+  const uint32_t *mult = mult_in;  // [n_rep][n_blocks]
+  if (block_maps) {
+    uint32_t *base = e->h_mult + (uint64_t)lead * n_blocks;
+    memset(base, 0, (uint64_t)n_rep * n_blocks * sizeof(uint32_t));
     for (uint32_t r = 0; r < n_rep; r++) {
-      uint32_t *m = e->h_mult + (uint64_t)r * n_blocks;
+      uint32_t *m = base + (uint64_t)r * n_blocks;
       const uint64_t *bm = block_maps + (uint64_t)r * n_blocks;
       for (uint64_t b = 0; b < n_blocks; b++) {
         if (bm[b] >= n_blocks) return fail(NGD_E_INVALID, "ngd_run: block_map entry out of range");
-        mult_max[r] = std::max(mult_max[r], ++m[bm[b]]);
+        mult_max[lead + r] = std::max(mult_max[lead + r], ++m[bm[b]]);
       }
-      drawn[r] = n_eff;
+      drawn[lead + r] = n_eff;
     }
-    mult = e->h_mult;
+    mult = base;
   } else {
     for (uint32_t r = 0; r < n_rep; r++)
       for (uint64_t b = 0; b < n_blocks; b++) {
         const uint32_t m = mult[(uint64_t)r * n_blocks + b];
-        mult_max[r] = std::max(mult_max[r], m);
-        drawn[r] += (unsigned long long)m * block_size;
+        mult_max[lead + r] = std::max(mult_max[lead + r], m);
+        drawn[lead + r] += (unsigned long long)m * block_size;
       }
+    if (lead) {
+      memcpy(e->h_mult + n_blocks, mult, (uint64_t)n_rep * n_blocks * sizeof(uint32_t));
+      mult = e->h_mult + n_blocks;
+    }
   }
+  if (lead) {
+    for (uint64_t b = 0; b < n_blocks; b++) e->h_mult[b] = 1u;
+    drawn[0] = g.n_sites;
+    mult_max[0] = 1;
+  }
+  double *rep_sum = d_sum + (uint64_t)lead * n_pairs;
+  unsigned long long *rep_cnt = d_cnt + (uint64_t)lead * n_pairs;
+
+  // 1. per-block partials; the full data set rides along as the all-ones row when the blocks cover every site
   bool feasible = false;
-  int rc = partials_impl(e, mult, drawn.data(), n_rep, n_blocks, block_size, d_sum, d_cnt, &feasible);
-  if (rc || feasible) return rc;
-  for (uint32_t r = 0; r < n_rep; r++) {  // one weighted accumulation pass per replicate
-    rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[r], n_blocks, block_size, drawn[r],
-                   d_sum + (uint64_t)r * n_pairs, d_cnt + (uint64_t)r * n_pairs, r > 0);
+  int rc;
+  if (lead && n_eff == g.n_sites) {
+    rc = partials_impl(e, e->h_mult, drawn.data(), n_rep + 1, n_blocks, block_size, d_sum, d_cnt, &feasible);
+    if (rc || feasible) return rc;
+  } else {
+    rc = partials_impl(e, mult, drawn.data() + lead, n_rep, n_blocks, block_size, rep_sum, rep_cnt, &feasible);
+    if (rc) return rc;
+    if (feasible) return lead ? pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, true) : NGD_OK;
+  }
+  // 2. EM kernels: many matrices per accumulation pass.  The faithful form keeps matrix 0 on the plain pass,
+  //    whose accumulation is the reference's term by term.
+  const bool em = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
+  if (em && n_rep + lead >= 2 && env_u64("NGD_EM_BATCH", 1)) {
+    const bool fold = lead && e->kernel == NGD_KERNEL_EM_FAST;
+    if (lead && !fold) {
+      rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
+      if (rc) return rc;
+    }
+    return em_batch_impl(e, mult, mult_max.data() + lead, drawn.data() + lead, n_rep, fold, n_blocks, block_size,
+                         fold ? d_sum : rep_sum, fold ? d_cnt : rep_cnt, lead && !fold);
+  }
+  // 3. one accumulation pass per matrix
+  if (lead) {
+    rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
+    if (rc) return rc;
+  }
+  for (uint32_t r = 0; r < n_rep; r++) {
+    rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[lead + r], n_blocks, block_size, drawn[lead + r],
+                   rep_sum + (uint64_t)r * n_pairs, rep_cnt + (uint64_t)r * n_pairs, lead || r > 0);
     if (rc) return rc;
   }
   return NGD_OK;
@@ -789,20 +899,20 @@ static int batch_buffers(ngd_engine *e, uint32_t n_rep) {
 int ngd_run_device(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size,
                    void *d_sum, void *d_cnt) {
   if (!d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_device: null output");
-  return run_impl(e, block_map, nullptr, block_map ? 1 : 0, n_blocks, block_size, (double *)d_sum,
+  return run_impl(e, block_map, nullptr, block_map ? 1 : 0, false, n_blocks, block_size, (double *)d_sum,
                   (unsigned long long *)d_cnt);
 }
 
 int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, void *d_sum,
                         void *d_cnt) {
   if (!d_sum || !d_cnt || !mult) return fail(NGD_E_INVALID, "ngd_run_mult_device: null argument");
-  return run_impl(e, nullptr, mult, 1, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, nullptr, mult, 1, false, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
 }
 
 int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_t block_size, double *sum,
                  uint64_t *cnt) {
   if (!e || !mult) return fail(NGD_E_INVALID, "ngd_run_mult: null argument");
-  int rc = run_impl(e, nullptr, mult, 1, n_blocks, block_size, e->d_sum, e->d_cnt);
+  int rc = run_impl(e, nullptr, mult, 1, false, n_blocks, block_size, e->d_sum, e->d_cnt);
   if (rc) return rc;
   return copy_out(e, 1, e->d_sum, e->d_cnt, sum, cnt);
 }
@@ -810,7 +920,7 @@ int ngd_run_mult(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks, uint64_
 int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_t block_size, double *sum,
             uint64_t *cnt) {
   if (!e) return fail(NGD_E_INVALID, "ngd_run: null engine");
-  int rc = run_impl(e, block_map, nullptr, block_map ? 1 : 0, n_blocks, block_size, e->d_sum, e->d_cnt);
+  int rc = run_impl(e, block_map, nullptr, block_map ? 1 : 0, false, n_blocks, block_size, e->d_sum, e->d_cnt);
   if (rc) return rc;
   return copy_out(e, 1, e->d_sum, e->d_cnt, sum, cnt);
 }
@@ -818,13 +928,13 @@ int ngd_run(ngd_engine *e, const uint64_t *block_map, uint64_t n_blocks, uint64_
 int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                          uint64_t block_size, void *d_sum, void *d_cnt) {
   if (!block_maps || !n_rep || !d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_batch_device: null argument");
-  return run_impl(e, block_maps, nullptr, n_rep, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, block_maps, nullptr, n_rep, false, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
 }
 
 int ngd_run_mult_batch_device(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks,
                               uint64_t block_size, void *d_sum, void *d_cnt) {
   if (!mult || !n_rep || !d_sum || !d_cnt) return fail(NGD_E_INVALID, "ngd_run_mult_batch_device: null argument");
-  return run_impl(e, nullptr, mult, n_rep, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
+  return run_impl(e, nullptr, mult, n_rep, false, n_blocks, block_size, (double *)d_sum, (unsigned long long *)d_cnt);
 }
 
 int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
@@ -832,7 +942,7 @@ int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uin
   if (!e || !block_maps || !n_rep) return fail(NGD_E_INVALID, "ngd_run_batch: null argument");
   int rc = batch_buffers(e, n_rep);
   if (rc) return rc;
-  rc = run_impl(e, block_maps, nullptr, n_rep, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  rc = run_impl(e, block_maps, nullptr, n_rep, false, n_blocks, block_size, e->d_bsum, e->d_bcnt);
   if (rc) return rc;
   return copy_out(e, n_rep, e->d_bsum, e->d_bcnt, sum, cnt);
 }
@@ -842,9 +952,26 @@ int ngd_run_mult_batch(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint
   if (!e || !mult || !n_rep) return fail(NGD_E_INVALID, "ngd_run_mult_batch: null argument");
   int rc = batch_buffers(e, n_rep);
   if (rc) return rc;
-  rc = run_impl(e, nullptr, mult, n_rep, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  rc = run_impl(e, nullptr, mult, n_rep, false, n_blocks, block_size, e->d_bsum, e->d_bcnt);
   if (rc) return rc;
   return copy_out(e, n_rep, e->d_bsum, e->d_bcnt, sum, cnt);
+}
+
+int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
+                       uint64_t block_size, void *d_sum, void *d_cnt) {
+  if (!d_sum || !d_cnt || (n_rep && !block_maps)) return fail(NGD_E_INVALID, "ngd_run_job_device: null argument");
+  return run_impl(e, block_maps, nullptr, n_rep, n_rep != 0, n_blocks, block_size, (double *)d_sum,
+                  (unsigned long long *)d_cnt);
+}
+
+int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                double *sum, uint64_t *cnt) {
+  if (!e || (n_rep && !block_maps)) return fail(NGD_E_INVALID, "ngd_run_job: null argument");
+  int rc = batch_buffers(e, n_rep + 1);
+  if (rc) return rc;
+  rc = run_impl(e, block_maps, nullptr, n_rep, n_rep != 0, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  if (rc) return rc;
+  return copy_out(e, n_rep + 1, e->d_bsum, e->d_bcnt, sum, cnt);
 }
 
 int ngd_drop_caches(ngd_engine *e) {

@@ -629,8 +629,10 @@ int main(int argc, char **argv) {
   FILE *out_fh = fopen(p.out, "w");
   if (!out_fh) die(__FUNCTION__, "cannot open output file!");
 
-  // Replicates go to the engine in batches (ngd_run_batch): the block maps of a batch are drawn up front, in
-  // the order rnd_map_data (ngsDist.cpp:416-437) would draw them -- nothing else consumes the generator.
+  // Matrices go to the engine in batches: the first batch is the full-data matrix plus the first replicates
+  // (ngd_run_job, which lets the engine share work between them), later ones replicates only (ngd_run_batch).
+  // The block maps of a batch are drawn up front, in the order rnd_map_data (ngsDist.cpp:416-437) would draw
+  // them -- nothing else consumes the generator.
   const uint64_t kBatch = 32;
   std::vector<double> sum, dist(n_comb);
   std::vector<uint64_t> cnt, block_maps;
@@ -640,17 +642,17 @@ int main(int argc, char **argv) {
   uint64_t n_sites = p.n_sites;
 
   // all engines, one host thread each; shards are disjoint, so merging is x + 0
-  auto run_all = [&](const uint64_t *maps, uint32_t n_rep, uint64_t n_blocks) {
-    const uint64_t n_mat = n_rep ? n_rep : 1;
+  auto run_all = [&](const uint64_t *maps, uint32_t n_rep, bool with_full, uint64_t n_blocks) {
+    const uint64_t n_mat = n_rep + (with_full ? 1 : 0);
     sum.assign(n_mat * n_comb, 0.0);
     cnt.assign(n_mat * n_comb, 0);
     auto run_one = [&](size_t r, double *s, uint64_t *c) {
-      return n_rep ? ngd_run_batch(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c)
-                   : ngd_run(eng.e[r], nullptr, 0, 0, s, c);
+      return with_full ? ngd_run_job(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c)
+                       : ngd_run_batch(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c);
     };
     if (eng.e.size() == 1) {
       int rc = run_one(0, sum.data(), cnt.data());
-      if (rc) die_engine(n_rep ? "ngd_run_batch" : "ngd_run", rc);
+      if (rc) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rc);
       return;
     }
     std::vector<std::vector<double>> ps(eng.e.size(), std::vector<double>(n_mat * n_comb));
@@ -660,25 +662,25 @@ int main(int argc, char **argv) {
     for (size_t r = 0; r < eng.e.size(); r++)
       th.emplace_back([&, r]() { rcs[r] = run_one(r, ps[r].data(), pc[r].data()); });
     for (auto &t : th) t.join();
-    for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine(n_rep ? "ngd_run_batch" : "ngd_run", rcs[r]);
+    for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rcs[r]);
     for (size_t r = 0; r < eng.e.size(); r++)
       for (uint64_t k = 0; k < n_mat * n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
   };
 
   fflush(stdout);
   for (uint64_t rep = 0; rep <= p.n_boot_rep;) {
-    uint64_t n_blocks = 0, n_in_batch = 1;
     const auto t_c0 = std::chrono::steady_clock::now();
-    if (rep > 0) {  // ngsDist.cpp:235-238
+    const bool with_full = rep == 0;
+    const uint64_t n_in_batch = std::min<uint64_t>(kBatch, p.n_boot_rep - rep + 1);  // matrices of this batch
+    const uint64_t n_boot_here = n_in_batch - (with_full ? 1 : 0);
+    uint64_t n_blocks = 0;
+    if (n_boot_here) {  // ngsDist.cpp:235-238
       n_sites -= n_sites % p.boot_block_size;
       n_blocks = n_sites / p.boot_block_size;
-      n_in_batch = std::min<uint64_t>(kBatch, p.n_boot_rep - rep + 1);
-      block_maps.resize(n_in_batch * n_blocks);
-      for (uint64_t r = 0; r < n_in_batch; r++) ngd_boot_block_map(rng, n_blocks, &block_maps[r * n_blocks]);
-      run_all(block_maps.data(), (uint32_t)n_in_batch, n_blocks);
-    } else {
-      run_all(nullptr, 0, 0);
+      block_maps.resize(n_boot_here * n_blocks);
+      for (uint64_t r = 0; r < n_boot_here; r++) ngd_boot_block_map(rng, n_blocks, &block_maps[r * n_blocks]);
     }
+    run_all(block_maps.data(), (uint32_t)n_boot_here, with_full, n_blocks);
     t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
 
     for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
@@ -689,7 +691,7 @@ int main(int argc, char **argv) {
       }
       if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
       if (rep > 0 && p.verbose >= 5) {
-        const uint64_t *bm = &block_maps[r * n_blocks];
+        const uint64_t *bm = &block_maps[(r - (with_full ? 1 : 0)) * n_blocks];
         for (uint64_t b = 0; b < n_blocks; b++)
           for (uint64_t s = 0; s < p.boot_block_size; s++)
             fprintf(stderr, "block: %lu\torig_site: %lu\trand_block:%lu\trand_site: %lu\n", b,

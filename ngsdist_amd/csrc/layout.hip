@@ -146,6 +146,26 @@ __global__ void k_expand(const uint32_t *__restrict__ mult, uint64_t n_eff, uint
   }
 }
 
+// W[s][RB] for the EM batch kernel: replicate r's multiplicity of site s (mult is [n_rep][n_blocks]); rows
+// r >= n_rep are zero; with lead_full, row 0 is the full data set instead: weight 1 on EVERY site
+__global__ void k_expand_batch(const uint32_t *__restrict__ mult, uint32_t n_rep, uint32_t rb, int lead_full,
+                               uint64_t n_blocks, uint64_t block_size, uint64_t n_sites, uint64_t n_sites_alloc,
+                               double *W) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_sites_alloc) return;
+  const uint64_t b = s / block_size;
+  const bool in_boot = b < n_blocks;
+  for (uint32_t r = 0; r < rb; r++) {
+    double w = 0.0;
+    if (lead_full && r == 0) w = s < n_sites ? 1.0 : 0.0;
+    else {
+      const uint32_t q = r - (lead_full ? 1u : 0u);
+      if (q < n_rep && in_boot) w = (double)mult[(uint64_t)q * n_blocks + b];
+    }
+    W[s * rb + r] = w;
+  }
+}
+
 // bit-planes of the per-site multiplicity, for weighted valid-site counts
 __global__ void k_planes(const uint32_t *__restrict__ ws, uint64_t n_sites, uint32_t n_words,
                          uint32_t n_planes, unsigned long long *planes) {
@@ -288,6 +308,13 @@ void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, 
                         const uint32_t *d_mult, uint32_t *d_ws, double *d_wk) {
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, d_mult,
                      n_blocks * block_size, block_size, n_sites, d_ws, d_wk);
+}
+
+void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n_rep, uint32_t rb, int lead_full,
+                              uint64_t n_blocks, uint64_t block_size, uint64_t n_sites, uint64_t n_sites_alloc,
+                              double *d_W) {
+  hipLaunchKernelGGL(k_expand_batch, dim3((unsigned)((n_sites_alloc + 255) / 256)), dim3(256), 0, st, d_mult, n_rep, rb,
+                     lead_full, n_blocks, block_size, n_sites, n_sites_alloc, d_W);
 }
 
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,

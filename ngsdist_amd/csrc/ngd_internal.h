@@ -85,6 +85,9 @@ void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, 
 uint32_t ngd_kg_count_blocks(uint64_t n_kg);
 void ngd_launch_kg_compact(hipStream_t st, const double *d_wk, uint64_t n_kg, uint32_t tail_kg, uint32_t *d_counts,
                            uint32_t *d_list);
+void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n_rep, uint32_t rb, int lead_full,
+                              uint64_t n_blocks, uint64_t block_size, uint64_t n_sites, uint64_t n_sites_alloc,
+                              double *d_W);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 
@@ -111,9 +114,17 @@ void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, co
                          const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
                          uint64_t sites_per_slice, double *slab);
 
+// rb (4, 8 or 16) replicates in one pass; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
+void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
+                               uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,
+                               const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
+                               uint64_t sites_per_slice, double *slab);
+
 // reduce.hip : deterministic slab reduction + valid-site counting
+// planes_per_slice: the slab holds that many result planes per slice (EM batch kernel), `slab` points at
+// the first slice's plane of the wanted result
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                       const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
+                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,

@@ -13,13 +13,13 @@ namespace {
 // ks goes to partial ks % 8) keep eight loads in flight per thread; they are combined in a fixed tree,
 // so the result is a fixed function of the slabs (deterministic), just not the left-to-right sum.
 __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab, uint32_t n_ks,
-                                                 const ngd_tile *__restrict__ tiles, uint32_t n_pad,
-                                                 uint64_t n_ind, double *__restrict__ d_sum) {
+                                                 uint32_t planes_per_slice, const ngd_tile *__restrict__ tiles,
+                                                 uint32_t n_pad, uint64_t n_ind, double *__restrict__ d_sum) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
   if (!(i < j && j < n_ind)) return;
-  const uint64_t plane = (uint64_t)n_pad * n_pad;
+  const uint64_t plane = (uint64_t)n_pad * n_pad * planes_per_slice;  // distance between consecutive slices
   const double *p = slab + (uint64_t)i * n_pad + j;
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t ks = 0;
@@ -235,10 +235,10 @@ void reduce_cb(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_
 }  // namespace
 
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                       const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
+                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
   if (!n_tiles) return;
-  hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, d_tiles, g.n_pad,
-                     g.n_ind, d_sum);
+  hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, planes_per_slice, d_tiles,
+                     g.n_pad, g.n_ind, d_sum);
 }
 
 // replicates per pass over the partials; the weight arrays are padded to a multiple of it

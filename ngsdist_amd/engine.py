@@ -170,6 +170,27 @@ class Engine:
                       c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
+    def run_job(self, block_maps=None, block_size=1, d_sum_ptr=None, d_cnt_ptr=None):
+        """the whole replicate loop in one call (ngd_run_job): matrix 0 = full data, then one matrix per row of
+        block_maps ([n_rep][n_blocks]); returns (sum, cnt) of shape [n_rep + 1][n_pairs]"""
+        if block_maps is None or len(block_maps) == 0:
+            a, ap, n_rep, n_blocks = None, None, 0, 0
+        else:
+            a = np.ascontiguousarray(block_maps, dtype=np.uint64)
+            if a.ndim != 2:
+                raise ValueError("expected [n_rep][n_blocks]")
+            ap = a.ctypes.data_as(C.POINTER(C.c_uint64))
+            n_rep, n_blocks = a.shape
+        if d_sum_ptr is not None:
+            _check(self._L.ngd_run_job_device(self._h, ap, n_rep, n_blocks, int(block_size), C.c_void_p(d_sum_ptr),
+                                              C.c_void_p(d_cnt_ptr)))
+            return None
+        s = np.empty((n_rep + 1, self.n_pairs), dtype=np.float64)
+        c = np.empty((n_rep + 1, self.n_pairs), dtype=np.uint64)
+        _check(self._L.ngd_run_job(self._h, ap, n_rep, n_blocks, int(block_size), s.ctypes.data_as(C.POINTER(C.c_double)),
+                                   c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return s, c
+
     def run_device(self, d_sum_ptr, d_cnt_ptr, block_map=None, block_size=1):
         """Results written to caller-owned device buffers (raw addresses)."""
         ptr, nb, bs, keep = self._map_args(block_map, block_size)

@@ -229,6 +229,44 @@ def test_bootstrap_batch_called_genotypes_bit_exact():
         assert np.array_equal(S[r], so) and np.array_equal(Cn[r], co)
 
 
+@pytest.mark.parametrize("kernel,block_size,pdel,partials", [
+    ("mfma", 8, True, True), ("mfma", 7, False, True), ("mfma", 1, True, True), ("stream", 3, False, True),
+    ("em_fast", 5, True, True), ("em_fast", 1, True, False), ("em_fast", 7, False, False),
+    ("em_faithful", 3, True, False), ("em_faithful", 12, False, True)])
+@pytest.mark.parametrize("n_rep", [0, 1, 5, 20])
+def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep, monkeypatch):
+    """ngd_run_job: matrix 0 = ngd_run(NULL) (counts exact, sums to rounding; bit-identical where the plan keeps the
+    plain pass), replicates bit-identical to ngd_run(block_map); whatever plan the engine picks: per-block partials
+    with the all-ones row (mfma 8 / em with partials on), the EM batch pass (partials off: what large data sets with
+    small blocks get), one list-driven weighted pass per replicate (mfma 7, 1), the streaming kernel."""
+    monkeypatch.setenv("NGD_BOOT_PARTIALS", "1" if partials else "0")
+    n_ind, n_sites = 21, 1203
+    indep = kernel in INDEP_KERNELS
+    p = O.synth_indmajor(31, n_ind, n_sites, miss_frac=0.2)
+    rng = N().Taus(5)
+    n_eff = n_sites - n_sites % block_size
+    maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)]) if n_rep else None
+    with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, block_size)
+        assert S.shape == (n_rep + 1, e.n_pairs)
+        s0, c0 = e.run()
+        assert np.array_equal(Cn[0], c0) and rel_err(S[0], s0) < 1e-12
+        for r in range(n_rep):
+            s1, c1 = e.run(maps[r], block_size)
+            assert np.array_equal(Cn[r + 1], c1)
+            assert np.array_equal(S[r + 1], s1)
+        if n_rep:  # and a batch without the leading matrix
+            S2, C2 = e.run_batch(maps, block_size)
+            assert np.array_equal(S2, S[1:]) and np.array_equal(C2, Cn[1:])
+    so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=indep, n_threads=8)
+    assert np.array_equal(Cn[0], co) and rel_err(S[0], so) < RTOL
+    if n_rep:
+        so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=indep, site_src=O.boot_site_src(maps[-1], block_size),
+                             n_sites=n_eff, n_threads=8)
+        assert np.array_equal(Cn[-1], co) and rel_err(S[-1], so) < RTOL
+
+
 def test_heavy_multiplicity_counts():
     """all blocks map to block 0 -> multiplicity n_blocks on a few sites (bit-plane path)."""
     n_ind, n_sites, B = 5, 640, 2
