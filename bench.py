@@ -72,7 +72,7 @@ def main():
     import torch.distributed as dist
 
     import ngsdist_amd as N
-    from ngsdist_amd.dist import merge_shards
+    from ngsdist_amd.dist import gather_matrices, merge_shards
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -158,7 +158,6 @@ def main():
         d_all = torch.zeros((n_mat, n_pairs), dtype=torch.float64, device=dev)
         h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
         cnt_mine = np.full(n_pairs, n_sites if rank == 0 else n_eff, dtype=np.uint64)
-        rows_dev, rows_host = list(d_all.unbind(0)), list(h_all.unbind(0))
     if batched:
         n_blocks = n_eff // W["block"]
         fold0 = n_eff == n_sites
@@ -197,12 +196,12 @@ def main():
                 N.finish(h_sum.numpy(), cnt_mine, 0, W["evol_model"], out=h_dist.numpy())
             if args.backend == "nccl":
                 d_dist.copy_(h_dist, non_blocking=True)
-                dist.all_gather(rows_dev, d_dist)
+                gather_matrices(d_all, d_dist)
                 if rank == 0:
                     h_all.copy_(d_all, non_blocking=True)
                     torch.cuda.synchronize()
             else:
-                dist.all_gather(rows_host, h_dist)
+                gather_matrices(h_all, h_dist)
             last["dist"] = h_all[-1].numpy()
             return
         if batched:
@@ -270,9 +269,9 @@ def main():
     if world > 1:  # communicator and buffers come up outside the timed region whatever --warmup is
         if by_reps:
             if args.backend == "nccl":
-                dist.all_gather(rows_dev, d_dist)
+                gather_matrices(d_all, d_dist)
             else:
-                dist.all_gather(rows_host, h_dist)
+                gather_matrices(h_all, h_dist)
         elif args.backend == "nccl":
             merge_shards(d_all if batched else d_sum, None, dst=0)
         else:

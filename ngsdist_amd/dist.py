@@ -1,6 +1,6 @@
-"""Multi-GPU plumbing: one process per GPU, pair tiles dealt over ranks, inputs
-replicated, and ONE collective at the end that brings the disjoint shards to
-rank 0.  Because every pair is owned by exactly one rank and the others hold
+"""Multi-GPU plumbing: one process per GPU and ONE collective per job.
+Replicate sharding (one finished matrix per rank): gather_matrices().
+Pair-tile / site sharding: merge_shards() brings the shards to rank 0.  Because every pair is owned by exactly one rank and the others hold
 exact zeros, a SUM reduce is a gather: x + 0 is exact in IEEE arithmetic (sums
 are >= +0, so no -0 ambiguity).  Backend "nccl" (= RCCL over xGMI) on GPUs,
 "gloo" in the CPU tests.
@@ -33,3 +33,13 @@ def merge_shards(sum_t, cnt_t, dst=0):
     dist.reduce(sum_t, dst=dst, op=dist.ReduceOp.SUM)
     if cnt_t is not None:
         dist.reduce(cnt_t, dst=dst, op=dist.ReduceOp.SUM)
+
+
+def gather_matrices(all_t, mine_t):
+    """Replicate sharding: rank r holds one finished matrix (mine_t, [n_pairs]); after the call every rank's
+    all_t ([world][n_pairs], same device and dtype) holds all of them, row r = rank r's.  One all-gather."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        all_t[0].copy_(mine_t)
+        return
+    dist.all_gather(list(all_t.unbind(0)), mine_t)

@@ -111,3 +111,46 @@ def test_shard_owner_covers_every_pair_once():
         assert o.min() >= 0 and o.max() < world
         if world <= 6:
             assert len(set(o.tolist())) == min(world, 6)
+
+
+def _replicate_worker(rank, world, port, n_ind, n_sites, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from ngsdist_amd.dist import gather_matrices
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's weak-scaling mode: rank 0 the full-data matrix, rank r the r-th bootstrap replicate (block size 1)
+    p = O.synth_indmajor(7, n_ind, n_sites)
+    rng = O.Taus(12345)
+    maps = [None] + [rng.block_map(n_sites) for _ in range(world - 1)]
+
+    def matrix(m):  # stand-in for the device kernels + the host tail
+        src = None if m is None else O.boot_site_src(m, 1)
+        s, c = O.all_pairs(p, site_src=src)
+        return O.finish(s, c, 0, 1)
+
+    mine = torch.from_numpy(matrix(maps[rank]))
+    all_t = torch.zeros((world, mine.numel()), dtype=torch.float64)
+    gather_matrices(all_t, mine)
+    if rank == 0:
+        q.put(all(np.array_equal(all_t[r].numpy(), matrix(maps[r])) for r in range(world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replicate_sharding_gathers_whole_matrices():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicate_worker, args=(r, 2, port, 12, 500, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    assert q.get(timeout=10)
