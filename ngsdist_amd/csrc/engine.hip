@@ -66,6 +66,10 @@ struct ngd_engine {
   double *slab_boot = nullptr;
   uint64_t boot_B = 0, boot_blocks = 0, boot_per_slice = 0, slab_boot_elems = 0;
   uint32_t boot_nks = 0, boot_sub = 0;
+  // a large slab costs ~12 ms per GB to allocate: until the passes it would have saved add up to that, calls are
+  // served without it (rent_ms = their estimated cost so far, for the geometry rent_B / rent_blocks)
+  double rent_ms = 0;
+  uint64_t rent_B = 0, rent_blocks = 0;
   uint32_t *cnt_boot = nullptr;  // per-block valid-site counts [n_blocks][n_pad][n_pad] (--pairwise_del)
   uint64_t cnt_B = 0, cnt_blocks = 0, cnt_boot_elems = 0;
   // per-call bootstrap weights (slice-major doubles / block-major uint32) and per-replicate site totals
@@ -634,12 +638,29 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   if (!cached || !c_cached) {
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)(total_b / 4));
     const uint64_t need = elems * 8 + c_elems * 4;
     const uint64_t have = e->slab_boot_elems * 8 + e->cnt_boot_elems * 4;
+    // default budget: most of what the device has left -- one pass over a slab of tens of GB still beats
+    // hundreds of accumulation passes
+    const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)((free_b + have) / 100 * 85));
     if (need > budget) return NGD_OK;
     if ((elems > e->slab_boot_elems || c_elems > e->cnt_boot_elems) && need + (1ull << 30) > free_b + have)
       return NGD_OK;
+    const double alloc_ms = need > have ? (double)(need - have) * 12e-9 : 0.0;
+    if (alloc_ms > 20.0 && env_u64("NGD_BOOT_PARTIALS", 1) < 2) {
+      // what this call costs without the partials: a list-driven pass per replicate (MFMA, ~3/4 of a pass)
+      // or a batch pass per 16 replicates (EM); rates are the measured ones of DESIGN.md section 6
+      const double ps = (double)e->n_owned_pairs * (double)n_eff;
+      const double pass_ms = mfma ? ps / 1.05e10 : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
+      const double alt_ms = mfma ? 0.75 * pass_ms * n_rep : 1.1 * pass_ms * ((n_rep + 15) / 16);
+      if (e->rent_B != block_size || e->rent_blocks != n_blocks) {
+        e->rent_B = block_size; e->rent_blocks = n_blocks; e->rent_ms = 0;
+      }
+      if (e->rent_ms + alt_ms < alloc_ms) {
+        e->rent_ms += alt_ms;
+        return NGD_OK;
+      }
+    }
   }
   *feasible = true;
 
