@@ -588,7 +588,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
-    ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles16, e->n_tiles16, d_cnt);
+    ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles, e->n_tiles, d_cnt);
   } else {
     ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, mult ? n_drawn : n_eff, nullptr, 1, d_cnt);
   }
@@ -779,14 +779,14 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
       if (!e->cfg.pairwise_del) {
         ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[q], nullptr, 1, cnt_r);
       } else if (is_lead) {
-        ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles16, e->n_tiles16, cnt_r);
+        ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles, e->n_tiles, cnt_r);
       } else {
         uint32_t n_planes = 0;
         while (n_planes < 32 && (mult_max[q] >> n_planes)) n_planes++;
         ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)(q - q0) * n_blocks, e->d_ws,
                            nullptr);
         ngd_launch_planes(e->st, e->d_ws, g.n_sites, g.n_words, n_planes, e->planes);
-        ngd_launch_count(e->st, g, e->mask, e->planes, n_planes, e->d_tiles16, e->n_tiles16, cnt_r);
+        ngd_launch_count(e->st, g, e->mask, e->planes, n_planes, e->d_tiles, e->n_tiles, cnt_r);
       }
     }
     HIPCHK(hipGetLastError());

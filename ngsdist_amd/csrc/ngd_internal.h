@@ -135,8 +135,8 @@ void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, u
 void ngd_launch_count_blocks(hipStream_t st, const ngd_geom &g, const unsigned long long *mask, uint64_t block_size,
                              uint32_t n_blocks, const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t *C);
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
-                      const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles16,
-                      uint32_t n_tiles16, unsigned long long *d_cnt);
+                      const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles,
+                      uint32_t n_tiles, unsigned long long *d_cnt);  // owned 128-tiles
 void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_tiles, uint32_t n_tiles,
                          unsigned long long value, const unsigned long long *d_values, uint32_t n_rep,
                          unsigned long long *d_cnt);

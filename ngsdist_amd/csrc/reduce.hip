@@ -139,22 +139,30 @@ __global__ __launch_bounds__(128) void k_fill_cnt(const ngd_tile *__restrict__ t
 
 constexpr int CW = 64;  // mask words staged per step
 
-// block = 16x16 pairs; LDS holds CW words of the 16+16 individuals (and planes).
+// Workgroup = 32 x 32 pairs of one 128-tile (grid = owned 128-tiles x 16 sub-tiles), thread = 2 x 2 pairs: four
+// LDS reads feed four popcounts (the one-pair-per-thread form was LDS-bandwidth bound: two reads per popcount).
+// LDS holds CW words of the 32 + 32 individuals (and of the planes).
 __global__ __launch_bounds__(256) void k_count(const unsigned long long *__restrict__ mask,
                                                 const unsigned long long *__restrict__ planes,
                                                 uint32_t n_planes, uint32_t n_words,
                                                 const ngd_tile *__restrict__ tiles, uint64_t n_ind,
                                                 unsigned long long *__restrict__ d_cnt) {
-  __shared__ unsigned long long mi[16][CW + 1], mj[16][CW + 1], pl[32][CW];
-  const uint32_t ig = tiles[blockIdx.x].ti, jg = tiles[blockIdx.x].tj;
+  __shared__ unsigned long long mi[32][CW + 1], mj[32][CW + 1], pl[32][CW];
+  const uint32_t tile = blockIdx.x >> 4, sa = (blockIdx.x >> 2) & 3, sb = blockIdx.x & 3;
+  const uint32_t ti = tiles[tile].ti, tj = tiles[tile].tj;
+  if (ti == tj && sa > sb) return;  // below the diagonal
+  const uint32_t i0 = ti * NGD_TILE + sa * 32, j0 = tj * NGD_TILE + sb * 32;
+  if (i0 >= n_ind || j0 >= n_ind) return;
   const uint32_t ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const uint32_t i = ig * 16 + ty, j = jg * 16 + tx;
-  unsigned long long cnt = 0;
-  for (uint32_t w0 = 0; w0 < n_words; w0 += CW) {
-    for (uint32_t t = threadIdx.x; t < 16 * CW; t += 256) {
+  unsigned long long cnt[2][2] = {{0, 0}, {0, 0}};
+  // grid.y splits the words (sites): integer atomics make the sum independent of the order
+  const uint32_t per_y = ((n_words + gridDim.y - 1) / gridDim.y + CW - 1) / CW * CW;
+  const uint32_t w_begin = blockIdx.y * per_y, w_end = w_begin + per_y < n_words ? w_begin + per_y : n_words;
+  for (uint32_t w0 = w_begin; w0 < w_end; w0 += CW) {
+    for (uint32_t t = threadIdx.x; t < 32 * CW; t += 256) {
       const uint32_t r = t / CW, c = t % CW;
       const uint32_t w = w0 + c;
-      const uint32_t ii = ig * 16 + r, jj = jg * 16 + r;
+      const uint32_t ii = i0 + r, jj = j0 + r;
       mi[r][c] = (w < n_words && ii < n_ind) ? mask[(uint64_t)ii * n_words + w] : 0ull;
       mj[r][c] = (w < n_words && jj < n_ind) ? mask[(uint64_t)jj * n_words + w] : 0ull;
     }
@@ -165,17 +173,34 @@ __global__ __launch_bounds__(256) void k_count(const unsigned long long *__restr
     }
     __syncthreads();
     if (n_planes == 0) {
-#pragma unroll 8
-      for (int c = 0; c < CW; c++) cnt += __popcll(mi[ty][c] & mj[tx][c]);
+      uint32_t q00 = 0, q01 = 0, q10 = 0, q11 = 0;  // at most 64 x CW per chunk: 32 bits are plenty
+#pragma unroll 4
+      for (int c = 0; c < CW; c++) {
+        const unsigned long long a0 = mi[ty][c], a1 = mi[ty + 16][c], b0 = mj[tx][c], b1 = mj[tx + 16][c];
+        q00 += __popcll(a0 & b0); q01 += __popcll(a0 & b1);
+        q10 += __popcll(a1 & b0); q11 += __popcll(a1 & b1);
+      }
+      cnt[0][0] += q00; cnt[0][1] += q01; cnt[1][0] += q10; cnt[1][1] += q11;
     } else {
       for (int c = 0; c < CW; c++) {
-        const unsigned long long m = mi[ty][c] & mj[tx][c];
-        for (uint32_t b = 0; b < n_planes; b++) cnt += (unsigned long long)__popcll(m & pl[b][c]) << b;
+        const unsigned long long a0 = mi[ty][c], a1 = mi[ty + 16][c], b0 = mj[tx][c], b1 = mj[tx + 16][c];
+        const unsigned long long m00 = a0 & b0, m01 = a0 & b1, m10 = a1 & b0, m11 = a1 & b1;
+        for (uint32_t b = 0; b < n_planes; b++) {
+          const unsigned long long p = pl[b][c];
+          cnt[0][0] += (unsigned long long)__popcll(m00 & p) << b; cnt[0][1] += (unsigned long long)__popcll(m01 & p) << b;
+          cnt[1][0] += (unsigned long long)__popcll(m10 & p) << b; cnt[1][1] += (unsigned long long)__popcll(m11 & p) << b;
+        }
       }
     }
     __syncthreads();
   }
-  if (i < j && j < n_ind) d_cnt[ngd_pair_idx(n_ind, i, j)] = cnt;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const uint32_t i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      if (i < j && j < n_ind) atomicAdd(&d_cnt[ngd_pair_idx(n_ind, i, j)], cnt[a][b]);  // d_cnt was zeroed
+    }
 }
 
 // Per-block valid-site counts C[b][i][j] = popcount(mask_i & mask_j over the sites of block b): the cnt half
@@ -284,9 +309,12 @@ void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_ti
 }
 
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
-                      const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles16,
-                      uint32_t n_tiles16, unsigned long long *d_cnt) {
-  if (!n_tiles16) return;
-  hipLaunchKernelGGL(k_count, dim3(n_tiles16), dim3(256), 0, st, mask, planes, n_planes, g.n_words,
-                     d_tiles16, g.n_ind, d_cnt);
+                      const unsigned long long *planes, uint32_t n_planes, const ngd_tile *d_tiles,
+                      uint32_t n_tiles, unsigned long long *d_cnt) {
+  if (!n_tiles) return;
+  // enough workgroups to fill the chip: split the sites when the pair tiles alone are too few
+  uint32_t ny = 1;
+  while ((uint64_t)n_tiles * 12 * ny < 8192 && (uint64_t)ny * 2 * CW <= g.n_words) ny *= 2;
+  hipLaunchKernelGGL(k_count, dim3(n_tiles * 16, ny), dim3(256), 0, st, mask, planes, n_planes, g.n_words, d_tiles,
+                     g.n_ind, d_cnt);
 }
