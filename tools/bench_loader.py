@@ -36,6 +36,9 @@ for prep in ("host", "device"):
     load = re.search(r"read \+ prepare \+ upload: ([0-9.]+) s", r.stderr).group(1)
     comp = re.search(r"distances: ([0-9.]+) s", r.stderr).group(1)
     outs[prep] = open("/tmp/ngd_loader_%s.dist" % prep).read()
+    for l in r.stderr.splitlines():
+        if "staged load" in l:
+            print("   ", l.strip())
     print("prep=%-6s wall %.3f s | read+prepare+upload %s s (%.2f GB/s of file) | distances %s s" % (
         prep, dt, load, os.path.getsize(path) / 1e9 / float(load), comp))
 print("outputs identical:", outs["host"] == outs["device"])
