@@ -104,19 +104,21 @@ __device__ __forceinline__ double site_fast(const double *g1, const double *g2, 
     Sm = Sn;
     Sc = Su;
   }
-  // Both candidates are scored and the RESULT is selected: selecting the inputs (g^T = even ? n : u)
-  // makes the compiler copy six registers at every loop exit, i.e. in every trip.
-  auto scored = [&](const double *a, const double *b, double S) {
-    double c = 0;
+  // g^T and S_T are selected AFTER the loop, through a flag the compiler cannot trace back to the loop exits
+  // (the empty asm): left to itself it turns the selection into register copies at both exits, i.e. into
+  // every trip of the loop.  One scoring and one divide per site instead of two.
+  asm volatile("" : "+v"(even));
+  double a[3], b[3];
 #pragma unroll
-    for (int x = 0; x < 3; x++) {
-      const double q = (sc.v[3 * x] * b[0] + sc.v[3 * x + 1] * b[1]) + sc.v[3 * x + 2] * b[2];
-      c += a[x] * q;
-    }
-    return c / S;
-  };
-  const double cu = scored(u1, u2, Sc), cn = scored(n1, n2, Sn);
-  return acc + (even ? cn : cu) * w;
+  for (int x = 0; x < 3; x++) { a[x] = even ? n1[x] : u1[x]; b[x] = even ? n2[x] : u2[x]; }
+  const double S = even ? Sn : Sc;
+  double c = 0;
+#pragma unroll
+  for (int x = 0; x < 3; x++) {
+    const double q = (sc.v[3 * x] * b[0] + sc.v[3 * x + 1] * b[1]) + sc.v[3 * x + 2] * b[2];
+    c += a[x] * q;
+  }
+  return acc + (c / S) * w;
 }
 
 template <bool FAST, bool WEIGHTED, bool PDEL>
