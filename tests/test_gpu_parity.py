@@ -481,3 +481,43 @@ def test_site_shards_bit_exact_for_called_genotypes_and_synth_ranges():
         with N().Engine(n_ind, hi - lo, kernel="mfma") as e:
             tot += e.synth_fill(9, 0.0, site0=lo).run()[0]
     assert rel_err(tot, so) < RTOL
+
+
+def test_random_shapes_flags_and_plans():
+    """a fixed-seed sweep over odd shapes: n_ind / n_sites around the padding edges (16, 64, 128), every kernel,
+    random flags, block sizes and replicate counts, partials on/off -- ngd_run_job against the oracle."""
+    rng = np.random.default_rng(20260)
+    kernels = INDEP_KERNELS + EM_KERNELS
+    old = os.environ.get("NGD_BOOT_PARTIALS")
+    try:
+        for case in range(28):
+            kernel = kernels[case % 4]
+            indep = kernel in INDEP_KERNELS
+            n_ind = int(rng.choice([2, 3, 15, 16, 17, 31, 33, 63, 65, 127, 129, 140]))
+            n_sites = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 257, 1000, 1025]))
+            pdel = bool(rng.integers(0, 2))
+            miss = float(rng.choice([0.0, 0.3]))
+            B = int(rng.choice([1, 2, 3, 4, 8, 12, 50]))
+            B = min(B, n_sites)
+            n_rep = int(rng.choice([0, 1, 2, 17]))
+            os.environ["NGD_BOOT_PARTIALS"] = str(int(rng.integers(0, 2)))
+            score = O.score_matrix(bool(rng.integers(0, 2)))
+            p = O.synth_indmajor(100 + case, n_ind, n_sites, miss_frac=miss)
+            n_eff = n_sites - n_sites % B
+            t = N().Taus(case)
+            maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
+            with N().Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
+                e.upload_ind_major(p).commit()
+                S, Cn = e.run_job(maps, B)
+            tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, os.environ["NGD_BOOT_PARTIALS"])
+            for m in sorted({0, n_rep}):
+                src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
+                so, co = O.all_pairs(p, score=score, pairwise_del=pdel, indep_geno=indep, site_src=src,
+                                     n_sites=n_sites if m == 0 else n_eff, n_threads=4)
+                assert np.array_equal(Cn[m], co), tag
+                assert rel_err(S[m], so) < RTOL, tag
+    finally:
+        if old is None:
+            os.environ.pop("NGD_BOOT_PARTIALS", None)
+        else:
+            os.environ["NGD_BOOT_PARTIALS"] = old
