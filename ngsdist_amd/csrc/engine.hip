@@ -347,6 +347,26 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     uint64_t ks = (want * (e->exact_shapes ? 4 : 1) + wg_per_slice - 1) / wg_per_slice;  // EXACT: 1-wave workgroups
     uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 128));
     ks = std::min(ks, max_ks);
+    ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
+    {
+      // Workgroups all last the same, so an XCD works through its share (n_wg * ks / 8 workgroups) in rounds of
+      // as many as it holds at a time, and a last round that is nearly empty costs as much as a full one
+      // ([measured] cfg 3, 34 workgroups per slice: ks = 232 -> 10.27 rounds, 47.5 ms; 240 -> 10.63, 46.1 ms;
+      // 248 -> 10.98, 44.65 ms).  Among the slice counts within 15 % of the target take the one whose last
+      // round is fullest.
+      hipDeviceProp_t prop;
+      const uint32_t cus_per_xcd = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8
+                                       ? (uint32_t)prop.multiProcessorCount / 8 : 32;
+      const double slots = (double)cus_per_xcd * (e->exact_shapes ? 12 : 3);
+      double best = 1e30;
+      uint64_t best_ks = ks;
+      for (uint64_t c = std::max<uint64_t>(8, ks * 85 / 100 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
+        const double rounds = (double)wg_per_slice * (double)(c / 8) / slots;
+        const double waste = std::ceil(rounds - 1e-9) / rounds + 1e-4 * std::fabs((double)c - (double)ks) / (double)ks;
+        if (waste < best) { best = waste; best_ks = c; }
+      }
+      if (env_u64("NGD_MFMA_ROUNDS", 1)) ks = best_ks;
+    }
     ks = env_u64("NGD_MFMA_KS", ks);
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     e->n_ks = (uint32_t)ks;
