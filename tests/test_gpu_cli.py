@@ -243,3 +243,31 @@ def test_bench_line_contract(tmp_path):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port"
     assert d["spot_check"]["max_rel_err_vs_oracle"] < 1e-9
+
+
+def test_binary_input_size_errors_and_gz_binary(tmp_path):
+    """plain binary files are read with pread on several threads, gz-compressed binary ones (and stdin) through
+    gzread: same bytes out; a file with trailing bytes is the reference's "not at EOF", a wrong size its
+    "invalid/corrupt" error."""
+    raw = np.fromfile(T_GL, dtype=np.float64)
+    base = ["--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno"]
+    exp = cli(tmp_path, "--geno", T_GL, *base)
+    for prep in ("host", "device"):
+        assert cli(tmp_path, "--geno", T_GL, *base, "--prep", prep, "--n_threads", 5) == exp
+    # trailing bytes (less than one site): passes the size check like the reference's integer division, then fails
+    tail = tmp_path / "tail.bin"
+    with open(str(tail), "wb") as fh:
+        fh.write(raw.tobytes() + b"\0" * 8)
+    for prep in ("host", "device"):
+        r = subprocess.run([BIN, "--geno", str(tail), "--probs", "--n_ind", "6", "--n_sites", "200", "--out",
+                            str(tmp_path / "o"), "--verbose", "0", "--prep", prep], capture_output=True)
+        assert r.returncode == 255 and b"not at EOF" in r.stderr
+    short = tmp_path / "short.bin"
+    raw[:-18].tofile(str(short))
+    r = subprocess.run([BIN, "--geno", str(short), "--probs", "--n_ind", "6", "--n_sites", "200", "--out",
+                        str(tmp_path / "o"), "--verbose", "0"], capture_output=True)
+    assert r.returncode == 255 and b"invalid/corrupt genotype input file" in r.stderr
+    # binary through stdin (gzread path)
+    with open(T_GL, "rb") as fh:
+        got = cli(tmp_path, "--geno", "-", *base, stdin=fh.read())
+    assert got == exp
