@@ -51,8 +51,8 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # the first two launches after the fill run at a lower clock
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
