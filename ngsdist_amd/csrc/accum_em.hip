@@ -112,12 +112,12 @@ __device__ __forceinline__ double site_fast(const double *g1, const double *g2, 
 #pragma unroll
   for (int x = 0; x < 3; x++) { a[x] = even ? n1[x] : u1[x]; b[x] = even ? n2[x] : u2[x]; }
   const double S = even ? Sn : Sc;
-  double c = 0;
+  // score-weighted sum of the 9 cells, fused multiply-adds (this form promises 1e-9, not the reference's bits)
+  double q[3];
 #pragma unroll
-  for (int x = 0; x < 3; x++) {
-    const double q = (sc.v[3 * x] * b[0] + sc.v[3 * x + 1] * b[1]) + sc.v[3 * x + 2] * b[2];
-    c += a[x] * q;
-  }
+  for (int x = 0; x < 3; x++)
+    q[x] = __builtin_fma(sc.v[3 * x + 2], b[2], __builtin_fma(sc.v[3 * x + 1], b[1], sc.v[3 * x] * b[0]));
+  const double c = __builtin_fma(a[2], q[2], __builtin_fma(a[1], q[1], a[0] * q[0]));
   return acc + (c / S) * w;
 }
 
