@@ -239,6 +239,9 @@ uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
  * the upper triangle, dealt by cost (off-diagonal tiles first) to the least loaded
  * shard -- the rule ngd_create() uses.  Pure host arithmetic. */
 uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world);
+/* free / total memory of a device (device < 0: the current one): lets a host decide whether a data set fits one
+ * engine or has to go through it a range of sites at a time (site sharding in time instead of across GPUs) */
+int ngd_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* bytes of device memory the engine holds for this configuration */
 uint64_t ngd_device_bytes(const ngd_engine *e);
 

@@ -132,6 +132,22 @@ int ngd_device_count(void) {
   return n;
 }
 
+int ngd_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(NGD_E_NODEVICE, "ngd_device_memory: no HIP device");
+  int cur = 0;
+  HIPCHK(hipGetDevice(&cur));
+  if (device < 0) device = cur;
+  if (device >= n) return fail(NGD_E_NODEVICE, "ngd_device_memory: device ordinal out of range");
+  HIPCHK(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  HIPCHK(hipMemGetInfo(&f, &t));
+  HIPCHK(hipSetDevice(cur));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return NGD_OK;
+}
+
 uint64_t ngd_n_pairs(uint64_t n_ind) { return n_ind * (n_ind - 1) / 2; }
 uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2) { return ngd_pair_idx(n_ind, i1, i2); }
 uint64_t ngd_device_bytes(const ngd_engine *e) { return e ? e->dev_bytes : 0; }

@@ -376,21 +376,27 @@ struct Engines {
   ~Engines() { for (auto *h : e) ngd_destroy(h); }
 };
 
-// read_geno(), read_data.cpp:13-116, fused with the preparation and the upload
-static void load_and_upload(const Pars &p, Engines &eng) {
-  const uint64_t n_ind = p.n_ind, n_sites = p.n_sites;
-  gzFile fh = open_gz(p.in_geno, p.in_bin ? "rb" : "r");
-  if (!fh) die("read_geno", "cannot open GENO file!");
-  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_sites, (64ull << 20) / (n_ind * 24)));
-  std::vector<double> buf(chunk * n_ind * 3);
-  bool in_logscale = p.in_logscale;
+// read_geno(), read_data.cpp:13-116, fused with the preparation and the upload.  The input is consumed front to
+// back in one or more parts (a data set larger than the device goes through it a range of sites at a time):
+// load() puts the next n_part sites into the engines as their sites 0 .. n_part-1 and commits them.
+struct Loader {
+  const Pars &p;
+  gzFile fh = nullptr;
+  int raw_fd = -1;
+  uint64_t raw_off = 0, raw_size = 0;
+  uint64_t done = 0;  // sites of the whole input consumed by earlier parts
+  bool eof = false;
+  explicit Loader(const Pars &pars);
+  void load(Engines &eng, uint64_t n_part, bool last_part);
+  void finish();
+};
 
-  const bool device_prep = p.in_bin && (p.prep == 2 || (p.prep == 0 && !p.call_geno));
+Loader::Loader(const Pars &pars) : p(pars) {
+  fh = open_gz(p.in_geno, p.in_bin ? "rb" : "r");
+  if (!fh) die("read_geno", "cannot open GENO file!");
   // A binary GL file that is a plain regular file (the usual case; gzread would only copy it through) is read
   // with pread() on several threads straight into the destination: one thread moves ~12 GB/s out of the page
   // cache, which is less than the copy to the device and the preparation kernel take.
-  int raw_fd = -1;
-  uint64_t raw_off = 0, raw_size = 0;
   if (p.in_bin && strcmp(p.in_geno, "-") != 0) {
     struct stat st;
     int fd = open(p.in_geno, O_RDONLY);
@@ -403,6 +409,14 @@ static void load_and_upload(const Pars &p, Engines &eng) {
       close(fd);
     }
   }
+}
+
+void Loader::load(Engines &eng, uint64_t n_part, bool last_part) {
+  const uint64_t n_ind = p.n_ind, n_sites = n_part;
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_sites, (64ull << 20) / (n_ind * 24)));
+  std::vector<double> buf(chunk * n_ind * 3);
+  bool in_logscale = p.in_logscale;
+  const bool device_prep = p.in_bin && (p.prep == 2 || (p.prep == 0 && !p.call_geno));
   const unsigned n_io = std::min(16u, std::max(4u, p.n_threads));
   auto read_exact = [&](double *dst, uint64_t bytes) {
     if (raw_fd >= 0) {
@@ -487,10 +501,10 @@ static void load_and_upload(const Pars &p, Engines &eng) {
     std::vector<std::vector<double>> toks(group);
     std::vector<int64_t> slot(group);  // site slot within the group, or -1
     uint64_t s = 0;
-    bool eof = false;
     while (s < n_sites) {
       lines.clear();
-      while (lines.size() < group && lines.size() < n_sites - s + 64) {  // a little read-ahead for header lines
+      // a little read-ahead for header lines -- in the last part only: lines past a part belong to the next one
+      while (lines.size() < group && lines.size() < n_sites - s + (last_part ? 64 : 0)) {
         if (gzgets(fh, line.data(), (int)line.size()) == nullptr) { eof = true; break; }
         chomp(line.data());
         lines.emplace_back(line.data());
@@ -510,7 +524,7 @@ static void load_and_upload(const Pars &p, Engines &eng) {
         if (s + filled == n_sites)  // anything after the last site: the reference stops reading before it
           die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
         if (!lines[k].empty()) {
-          if (toks[k].empty() || (s + filled == 0 && toks[k].size() < need)) {  // header
+          if (toks[k].empty() || (done + s + filled == 0 && toks[k].size() < need)) {  // header
             fprintf(stderr, "> Header found! Skipping line...\n");
             continue;
           }
@@ -558,6 +572,11 @@ static void load_and_upload(const Pars &p, Engines &eng) {
       if (eof && s < n_sites) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
     }
   }
+  done += n_part;
+  eng.commit();
+}
+
+void Loader::finish() {
   if (raw_fd >= 0) {
     if (raw_off != raw_size) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
     close(raw_fd);
@@ -567,7 +586,12 @@ static void load_and_upload(const Pars &p, Engines &eng) {
     if (!gzeof(fh)) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
   }
   gzclose(fh);
-  eng.commit();
+}
+
+static void load_and_upload(const Pars &p, Engines &eng) {
+  Loader L(p);
+  L.load(eng, p.n_sites, true);
+  L.finish();
 }
 
 int main(int argc, char **argv) {
@@ -647,33 +671,42 @@ int main(int argc, char **argv) {
   // NGD_HOST_SAME_DEVICE=1: every shard on --device (rehearses the multi-GPU merge on a 1-GPU box)
   const bool same_device = getenv("NGD_HOST_SAME_DEVICE") && atoi(getenv("NGD_HOST_SAME_DEVICE")) != 0;
   if (p.device + (same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
-  Engines eng;
-  for (int r = 0; r < p.n_gpus; r++) {
-    ngd_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.n_ind = p.n_ind;
-    cfg.n_sites = p.n_sites;
-    memcpy(cfg.score, p.score, sizeof(cfg.score));
-    cfg.pairwise_del = p.pairwise_del;
-    cfg.indep_geno = p.indep_geno;
-    cfg.device = same_device ? p.device : p.device + r;
-    cfg.kernel = p.kernel;
-    cfg.shard_rank = (uint32_t)r;
-    cfg.shard_world = (uint32_t)p.n_gpus;
-    ngd_engine *h = nullptr;
-    int rc = ngd_create(&cfg, &h);
-    if (rc) die_engine("ngd_create", rc);
-    eng.e.push_back(h);
-  }
+  auto make_engines = [&](Engines &eng, uint64_t n_sites_part, int n_gpus) {
+    for (int r = 0; r < n_gpus; r++) {
+      ngd_config cfg;
+      memset(&cfg, 0, sizeof(cfg));
+      cfg.n_ind = p.n_ind;
+      cfg.n_sites = n_sites_part;
+      memcpy(cfg.score, p.score, sizeof(cfg.score));
+      cfg.pairwise_del = p.pairwise_del;
+      cfg.indep_geno = p.indep_geno;
+      cfg.device = same_device ? p.device : p.device + r;
+      cfg.kernel = p.kernel;
+      cfg.shard_rank = (uint32_t)r;
+      cfg.shard_world = (uint32_t)n_gpus;
+      ngd_engine *h = nullptr;
+      int rc = ngd_create(&cfg, &h);
+      if (rc) die_engine("ngd_create", rc);
+      eng.e.push_back(h);
+    }
+  };
 
-  if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
-  const auto t_load0 = std::chrono::steady_clock::now();
-  load_and_upload(p, eng);
-  const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
-  if (p.verbose >= 2)
-    fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident per device)\n", t_load,
-            (double)p.n_ind * p.n_sites * 24 / 1e9);
-  double t_compute = 0, t_write = 0;
+  // Does the data set fit the device?  Resident bytes per site: both operand images (one on the EM path, the
+  // individual-major copy for the streaming kernel), masks and bootstrap weights; plus slabs and results.  If not,
+  // the input goes through ONE engine a range of sites at a time and the per-range (sum, cnt) are added (the site
+  // axis sharded in time; include/ngsdist_amd.h "Site sharding").
+  const uint64_t n_pad = (p.n_ind + 127) / 128 * 128;
+  const bool mfma_path = p.indep_geno && p.kernel != NGD_KERNEL_STREAM;
+  const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path ? 48 : 24) * n_pad) +
+                            (p.pairwise_del ? p.n_ind / 8 + 1 : 0) + 40;
+  const uint64_t n_t = n_pad / 128, n_slabs = std::max<uint64_t>(8, std::min<uint64_t>(256, 8192 / (n_t * (n_t + 1) / 2)));
+  const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);
+  uint64_t dev_free = 0, dev_total = 0;
+  if (ngd_device_memory(p.device, &dev_free, &dev_total)) die_engine("ngd_device_memory", -1);
+  uint64_t budget = dev_free / 100 * 85;
+  if (getenv("NGD_HOST_MAX_BYTES")) budget = strtoull(getenv("NGD_HOST_MAX_BYTES"), nullptr, 10);
+  const bool in_parts = fixed + per_site * p.n_sites > budget;
+  if (in_parts && p.n_gpus > 1) die(__FUNCTION__, "the data set does not fit one device; --n_gpus replicates it (use one GPU)");
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];
@@ -682,16 +715,138 @@ int main(int argc, char **argv) {
   FILE *out_fh = fopen(p.out, "w");
   if (!out_fh) die(__FUNCTION__, "cannot open output file!");
 
+  double t_compute = 0, t_write = 0;
+  std::vector<double> dist(n_comb);
+  std::vector<const char *> label_ptr;
+  for (auto &l : labels) label_ptr.push_back(l.c_str());
+  std::vector<char> text;
+
+  // one matrix of the output: the reference's progress lines in its order (:218-241, :281), the tail of gen_dist
+  // and the print block
+  auto emit = [&](uint64_t rep, const double *rs, const uint64_t *rc_, const uint64_t *bm, uint64_t n_blocks) {
+    if (p.verbose >= 1) {
+      if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
+      else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
+    }
+    if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
+    if (rep > 0 && bm && p.verbose >= 5) {
+      for (uint64_t b = 0; b < n_blocks; b++)
+        for (uint64_t s = 0; s < p.boot_block_size; s++)
+          fprintf(stderr, "block: %lu\torig_site: %lu\trand_block:%lu\trand_site: %lu\n", b,
+                  b * p.boot_block_size + s, bm[b], bm[b] * p.boot_block_size + s);
+    }
+    if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
+    if (p.verbose >= 3) {  // the per-pair line of ngsDist.cpp:366-367
+      uint64_t k = 0;
+      for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
+        for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
+          fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
+                  rs[k], rc_[k], rs[k] / (double)rc_[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
+    }
+    const auto t_f0 = std::chrono::steady_clock::now();
+    int rc = ngd_finish(rs, rc_, n_comb, p.tot_sites, p.evol_model, dist.data());
+    if (rc) die("gen_dist", "invalid evolutionary model specified!");
+    t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
+
+    if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
+    // ngsDist.cpp:282-287 (join(), gen_func.cpp:479-496); rows formatted in parallel, same bytes
+    const auto t_w0 = std::chrono::steady_clock::now();
+    if (text.empty()) text.resize(64 + p.n_ind * (p.n_ind * 16 + 64));
+    int64_t need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+    if (need > (int64_t)text.size()) {
+      text.resize((size_t)need);
+      need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+    }
+    if (need < 0) die(__FUNCTION__, "cannot format the distance matrix");
+    if (fwrite(text.data(), 1, (size_t)need, out_fh) != (size_t)need) die(__FUNCTION__, "cannot write output file!");
+    t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
+  };
+
+  const uint64_t kBatch = 32;
+  fflush(stdout);
+  if (in_parts) {
+    // ---- the data set is larger than the device: ranges of sites through one engine, sums added ----
+    const uint64_t B = p.boot_block_size;
+    const uint64_t n_eff = p.n_boot_rep ? p.n_sites - p.n_sites % B : 0, n_blocks = p.n_boot_rep ? n_eff / B : 0;
+    uint64_t unit = 16;  // ranges are whole 16-site groups and whole bootstrap blocks
+    if (p.n_boot_rep) { uint64_t a = 16, b = B; while (b) { uint64_t t = a % b; a = b; b = t; } unit = 16 / a * B; }
+    if (budget <= fixed || (budget - fixed) / per_site < unit)
+      die(__FUNCTION__, "not even one range of sites (16 sites / one bootstrap block) fits the device");
+    const uint64_t part = (budget - fixed) / per_site / unit * unit;
+    const uint64_t n_parts = (p.n_sites + part - 1) / part;
+    if (p.verbose >= 1)
+      fprintf(stderr, "==> Data set larger than the device budget (%.1f GB): %lu ranges of up to %lu sites\n", budget / 1e9,
+              n_parts, part);
+    // every replicate's block multiplicities, drawn in the reference's order before any data is read
+    std::vector<uint32_t> mult((uint64_t)p.n_boot_rep * n_blocks, 0);
+    std::vector<uint64_t> maps_kept;
+    {
+      std::vector<uint64_t> bm(n_blocks);
+      for (uint64_t r = 0; r < p.n_boot_rep; r++) {
+        ngd_boot_block_map(rng, n_blocks, bm.data());
+        for (uint64_t b = 0; b < n_blocks; b++) mult[r * n_blocks + bm[b]]++;
+        if (p.verbose >= 5) maps_kept.insert(maps_kept.end(), bm.begin(), bm.end());
+      }
+    }
+    const uint64_t n_mat = p.n_boot_rep + 1;
+    std::vector<double> tot_sum(n_mat * n_comb, 0.0), ps;
+    std::vector<uint64_t> tot_cnt(n_mat * n_comb, 0), pc;
+    std::vector<uint32_t> mpart;
+    if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
+    Loader L(p);
+    double t_load = 0;
+    for (uint64_t c0 = 0; c0 < p.n_sites; c0 += part) {
+      const uint64_t c1 = std::min(p.n_sites, c0 + part);
+      Engines eng;
+      make_engines(eng, c1 - c0, 1);
+      const auto t_l0 = std::chrono::steady_clock::now();
+      L.load(eng, c1 - c0, c1 == p.n_sites);
+      t_load += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_l0).count();
+      const auto t_c0 = std::chrono::steady_clock::now();
+      ps.resize(kBatch * n_comb); pc.resize(kBatch * n_comb);
+      int rc = ngd_run(eng.e[0], nullptr, 0, 0, ps.data(), pc.data());
+      if (rc) die_engine("ngd_run", rc);
+      for (uint64_t k = 0; k < n_comb; k++) { tot_sum[k] += ps[k]; tot_cnt[k] += pc[k]; }
+      const uint64_t blk_lo = std::min(c0, n_eff) / (B ? B : 1), blk_hi = std::min(c1, n_eff) / (B ? B : 1);
+      const uint64_t nb = blk_hi - blk_lo;  // this range's blocks (none in a range of tail sites only)
+      for (uint64_t r0 = 0; nb && r0 < p.n_boot_rep; r0 += kBatch) {
+        const uint64_t nr = std::min<uint64_t>(kBatch, p.n_boot_rep - r0);
+        mpart.resize(nr * nb);
+        for (uint64_t r = 0; r < nr; r++)
+          memcpy(&mpart[r * nb], &mult[(r0 + r) * n_blocks + blk_lo], nb * sizeof(uint32_t));
+        rc = ngd_run_mult_batch(eng.e[0], mpart.data(), (uint32_t)nr, nb, B, ps.data(), pc.data());
+        if (rc) die_engine("ngd_run_mult_batch", rc);
+        for (uint64_t k = 0; k < nr * n_comb; k++) {
+          tot_sum[(1 + r0) * n_comb + k] += ps[k];
+          tot_cnt[(1 + r0) * n_comb + k] += pc[k];
+        }
+      }
+      t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
+    }
+    L.finish();
+    if (p.verbose >= 2)
+      fprintf(stderr, "> read + prepare + upload: %.3f s in %lu ranges (%.2f GB of prepared input in all)\n", t_load, n_parts,
+              (double)p.n_ind * p.n_sites * 24 / 1e9);
+    for (uint64_t rep = 0; rep < n_mat; rep++)
+      emit(rep, &tot_sum[rep * n_comb], &tot_cnt[rep * n_comb],
+           rep && !maps_kept.empty() ? &maps_kept[(rep - 1) * n_blocks] : nullptr, n_blocks);
+  } else {
+  Engines eng;
+  make_engines(eng, p.n_sites, p.n_gpus);
+  if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
+  const auto t_load0 = std::chrono::steady_clock::now();
+  load_and_upload(p, eng);
+  const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
+  if (p.verbose >= 2)
+    fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident per device)\n", t_load,
+            (double)p.n_ind * p.n_sites * 24 / 1e9);
+
   // Matrices go to the engine in batches: the first batch is the full-data matrix plus the first replicates
   // (ngd_run_job, which lets the engine share work between them), later ones replicates only (ngd_run_batch).
   // The block maps of a batch are drawn up front, in the order rnd_map_data (ngsDist.cpp:416-437) would draw
   // them -- nothing else consumes the generator.
-  const uint64_t kBatch = 32;
-  std::vector<double> sum, dist(n_comb);
+  std::vector<double> sum;
   std::vector<uint64_t> cnt, block_maps;
-  std::vector<const char *> label_ptr;
-  for (auto &l : labels) label_ptr.push_back(l.c_str());
-  std::vector<char> text;
   uint64_t n_sites = p.n_sites;
 
   // all engines, one host thread each; shards are disjoint, so merging is x + 0
@@ -720,7 +875,6 @@ int main(int argc, char **argv) {
       for (uint64_t k = 0; k < n_mat * n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
   };
 
-  fflush(stdout);
   for (uint64_t rep = 0; rep <= p.n_boot_rep;) {
     const auto t_c0 = std::chrono::steady_clock::now();
     const bool with_full = rep == 0;
@@ -735,49 +889,10 @@ int main(int argc, char **argv) {
     }
     run_all(block_maps.data(), (uint32_t)n_boot_here, with_full, n_blocks);
     t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
-
-    for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
-      // the reference's progress lines, in its order (:218-241, :281)
-      if (p.verbose >= 1) {
-        if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
-        else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
-      }
-      if (p.verbose >= 2) fprintf(stderr, "> Mapping positions...\n");
-      if (rep > 0 && p.verbose >= 5) {
-        const uint64_t *bm = &block_maps[(r - (with_full ? 1 : 0)) * n_blocks];
-        for (uint64_t b = 0; b < n_blocks; b++)
-          for (uint64_t s = 0; s < p.boot_block_size; s++)
-            fprintf(stderr, "block: %lu\torig_site: %lu\trand_block:%lu\trand_site: %lu\n", b,
-                    b * p.boot_block_size + s, bm[b], bm[b] * p.boot_block_size + s);
-      }
-      if (p.verbose >= 2) fprintf(stderr, "> Calculating pairwise genetic distances...\n");
-      const double *rs = &sum[r * n_comb];
-      const uint64_t *rc_ = &cnt[r * n_comb];
-      if (p.verbose >= 3) {  // the per-pair line of ngsDist.cpp:366-367
-        uint64_t k = 0;
-        for (uint64_t i1 = 0; i1 < p.n_ind; i1++)
-          for (uint64_t i2 = i1 + 1; i2 < p.n_ind; i2++, k++)
-            fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
-                    rs[k], rc_[k], rs[k] / (double)rc_[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
-      }
-      const auto t_f0 = std::chrono::steady_clock::now();
-      int rc = ngd_finish(rs, rc_, n_comb, p.tot_sites, p.evol_model, dist.data());
-      if (rc) die("gen_dist", "invalid evolutionary model specified!");
-      t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
-
-      if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
-      // ngsDist.cpp:282-287 (join(), gen_func.cpp:479-496); rows formatted in parallel, same bytes
-      const auto t_w0 = std::chrono::steady_clock::now();
-      if (text.empty()) text.resize(64 + p.n_ind * (p.n_ind * 16 + 64));
-      int64_t need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
-      if (need > (int64_t)text.size()) {
-        text.resize((size_t)need);
-        need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
-      }
-      if (need < 0) die(__FUNCTION__, "cannot format the distance matrix");
-      if (fwrite(text.data(), 1, (size_t)need, out_fh) != (size_t)need) die(__FUNCTION__, "cannot write output file!");
-      t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
-    }
+    for (uint64_t r = 0; r < n_in_batch; r++, rep++)
+      emit(rep, &sum[r * n_comb], &cnt[r * n_comb],
+           rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks);
+  }
   }
   fclose(out_fh);
   if (p.verbose >= 2)

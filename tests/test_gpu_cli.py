@@ -271,3 +271,33 @@ def test_binary_input_size_errors_and_gz_binary(tmp_path):
     with open(T_GL, "rb") as fh:
         got = cli(tmp_path, "--geno", "-", *base, stdin=fh.read())
     assert got == exp
+
+
+def test_data_set_larger_than_the_device_goes_through_in_ranges(tmp_path, monkeypatch):
+    """NGD_HOST_MAX_BYTES below the data set's footprint: the host sends ranges of sites through one engine and
+    adds the per-range (sum, cnt).  Called genotypes (every term dyadic): byte-identical to the one-engine run,
+    bootstrap replicates, --pairwise_del and text input included; GL data on the EM path: equal to 1e-9."""
+    path, lpath, labels = _testA_like(tmp_path)
+    base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345]
+    # footprint model of the host: 512 MiB + slabs + 64 B per pair fixed, ~6.2 KB per site at 24 individuals
+    small = str((512 << 20) + 256 * 128 * 128 * 8 + 276 * 64 + 6200 * 2600)
+    for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--n_boot_rep", 2, "--n_threads", 3]):
+        monkeypatch.delenv("NGD_HOST_MAX_BYTES", raising=False)
+        whole = cli(tmp_path, *base, *extra)
+        monkeypatch.setenv("NGD_HOST_MAX_BYTES", small)
+        r = subprocess.run([BIN] + [str(a) for a in base + extra] + ["--out", str(tmp_path / "parts.dist"), "--verbose", "1"],
+                           capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        assert b"larger than the device budget" in r.stderr and b" 4 ranges" in r.stderr
+        assert open(str(tmp_path / "parts.dist")).read() == whole
+    # binary GL input, EM path, bootstrap with 16-site blocks: numerically equal
+    gl = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--n_boot_rep", 2, "--boot_block_size", 16, "--seed", 5]
+    monkeypatch.delenv("NGD_HOST_MAX_BYTES", raising=False)
+    whole = cli(tmp_path, *gl)
+    monkeypatch.setenv("NGD_HOST_MAX_BYTES", str((512 << 20) + 256 * 128 * 128 * 8 + 15 * 64 + 3200 * 70))
+    parts = cli(tmp_path, *gl, name="p2.dist")
+
+    def cells(t):
+        return np.array([float(x) for ln in t.splitlines() if "\t" in ln for x in ln.split("\t")[1:]])
+    a, b = cells(whole), cells(parts)
+    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-10)
