@@ -172,9 +172,10 @@ int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
  * (site sharding, as ngd_run_mult).  Outputs are [n_rep][n_pairs].  The engine computes per-block partial
  * (sum, cnt) once and forms up to 32 replicates per pass over them, so a batch costs little more than
  * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run().
- * When the partials do not apply (streaming kernel, MFMA kernel with block_size % 4 != 0, not enough
- * device memory) this is n_rep weighted accumulation passes on the --indep_geno path (each walks only the
- * sites its replicate drew) and one pass per 16 replicates on the EM path. */
+ * When the partials do not apply (streaming kernel, not enough device memory for one partial result per
+ * block -- e.g. block size 1 on a large data set) this is n_rep weighted accumulation passes on the
+ * --indep_geno path (each walks only the sites its replicate drew) and one pass per 16 replicates on the
+ * EM path. */
 int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                   uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,

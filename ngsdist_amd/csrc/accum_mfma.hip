@@ -54,7 +54,8 @@ template <bool WEIGHTED, int DEPTH, int WPS, bool EXACT>
 __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
-    uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, double *__restrict__ slab) {
+    uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, uint64_t k_per_slice, uint32_t w_slice_stride,
+    double *__restrict__ slab) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
   const uint32_t xcd = b & 7u, q = b >> 3;
@@ -69,9 +70,23 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const uint32_t shape = __builtin_amdgcn_readfirstlane((uint32_t)job.rows | ((uint32_t)job.cols << 3) |
                                                         ((uint32_t)job.tri << 6));
 
-  const uint64_t kg0 = (uint64_t)ks * kg_per_slice;
+  // A slice is kg_per_slice whole k-groups -- or, for bootstrap blocks that are not whole k-groups
+  // (k_per_slice != 0: a block of B sites is 3 B contraction indices), every k-group the block touches,
+  // with per-slice weights (1 inside the block, 0 outside; w_slice_stride k-groups of them per slice)
+  // masking the indices that the first and last k-group share with the neighbouring blocks.
+  uint64_t kg0 = (uint64_t)ks * kg_per_slice;
   uint64_t kg1 = kg0 + kg_per_slice;
+  if (k_per_slice) {
+    kg0 = ((uint64_t)ks * k_per_slice) >> 2;
+    kg1 = ((uint64_t)(ks + 1) * k_per_slice + 3) >> 2;
+  }
   if (kg1 > n_kg) kg1 = n_kg;
+  const double *wk_s = wk;  // weight of real k-group kg: wk_s + (kg - wk_kg0) * 4
+  uint64_t wk_kg0 = 0;
+  if (WEIGHTED && w_slice_stride) {
+    wk_s = wk + (uint64_t)ks * w_slice_stride * 4;
+    wk_kg0 = kg0;
+  }
 
   ngd_d4 acc[WM][WN];
 #pragma unroll
@@ -107,7 +122,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   // WEIGHTED (one bootstrap replicate): the slice is a range of the LIST of k-groups that have a non-zero
   // weight (layout.hip); kidx() maps a list position to the k-group, a scalar load issued one trip ahead of
   // the fetch that needs it.  Every job of a slice walks the same list, so the slice still moves as one.
-  auto kidx = [&](uint64_t pos) -> uint64_t { return WEIGHTED ? (uint64_t)kgl[pos] : pos; };
+  auto kidx = [&](uint64_t pos) -> uint64_t { return (WEIGHTED && kgl) ? (uint64_t)kgl[pos] : pos; };
   auto fetch = [&](int d, uint64_t kg) {
     const double *xa = pa + kg * kstride;
     const double *xb = pb + kg * kstride;
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
         : "=&v"(bq[d][0]), "=&v"(bq[d][1]), "=&v"(bq[d][2]), "=&v"(bq[d][3])
         : "v"(lane_off), "s"(xb));
     if (WEIGHTED) {
-      const double *xw = wk + kg * 4;
+      const double *xw = wk_s + (kg - wk_kg0) * 4;
       asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(wq[d]) : "v"(lane_wk), "s"(xw));
     }
   };
@@ -197,7 +212,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
       if (PN > 2) load_frag<1024>(bq[d][2], lane_off, xb);
       if (PN > 3) load_frag<1536>(bq[d][3], lane_off, xb);
       if (WEIGHTED) {
-        const double *xw = wk + kg * 4;
+        const double *xw = wk_s + (kg - wk_kg0) * 4;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(wq[d]) : "v"(lwk), "s"(xw));
       }
     };
@@ -283,7 +298,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
-                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab) {
+                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
+                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab) {
   if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)
   static const int variant = [] {
@@ -294,7 +310,7 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
   // wavefront that is done should not wait for three siblings before its slot is handed on
 #define NGD_MFMA(W, D, P, X)                                                                                    \
   hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
-                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, slab)
+                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab)
   // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
   // (profiles/r01_*): the third wavefront covers the others' load phases.
   // variant 1: 4-deep register ring, 2 wavefronts per SIMD.

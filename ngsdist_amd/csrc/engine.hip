@@ -70,6 +70,8 @@ struct ngd_engine {
   // served without it (rent_ms = their estimated cost so far, for the geometry rent_B / rent_blocks)
   double rent_ms = 0;
   uint64_t rent_B = 0, rent_blocks = 0;
+  double *d_wslice = nullptr;    // 0/1 weights per slice, bootstrap blocks that are not whole k-groups
+  uint64_t cap_wslice = 0;
   uint32_t *cnt_boot = nullptr;  // per-block valid-site counts [n_blocks][n_pad][n_pad] (--pairwise_del)
   uint64_t cnt_B = 0, cnt_blocks = 0, cnt_boot_elems = 0;
   // per-call bootstrap weights (slice-major doubles / block-major uint32) and per-replicate site totals
@@ -158,7 +160,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -538,16 +540,20 @@ int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) { return ngd_
 
 // w != NULL: one bootstrap replicate; for the MFMA kernel kgl is then the list of k-groups to visit and
 // per_slice / kg_lim count list entries
+// k_per_slice != 0 (MFMA, bootstrap blocks that are not whole k-groups): slices of k_per_slice contraction indices,
+// masked by the per-slice 0/1 weights in e->d_wslice (w_stride k-groups per slice)
 static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *kgl, uint64_t sites_eff, uint32_t n_ks,
-                              uint64_t per_slice, uint64_t kg_lim, double *slab) {
+                              uint64_t per_slice, uint64_t kg_lim, double *slab, uint64_t k_per_slice = 0,
+                              uint32_t w_stride = 0) {
   const ngd_geom &g = e->g;
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
       if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
         ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
       else
-        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, w ? e->d_wk : nullptr, w ? kgl : nullptr, e->d_jobs, e->n_wg,
-                              e->exact_shapes, n_ks, per_slice, kg_lim, slab);
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
+                              (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
+                              kg_lim, k_per_slice, w_stride, slab);
       break;
     default:
       ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -651,7 +657,11 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   const bool pdel = e->cfg.pairwise_del != 0;
   *feasible = false;
   if (e->kernel == NGD_KERNEL_STREAM || !env_u64("NGD_BOOT_PARTIALS", 1)) return NGD_OK;
-  if (mfma && (block_size % 4 != 0 || env_u64("NGD_MFMA_VARIANT", 0) >= 2)) return NGD_OK;
+  if (mfma && env_u64("NGD_MFMA_VARIANT", 0) >= 2) return NGD_OK;
+  // MFMA slices are whole k-groups of 4 contraction indices; a block of B sites is 3 B of them.  Blocks that are not
+  // whole k-groups become slices of every k-group they touch, the shared first / last k-group masked per slice.
+  const bool unaligned = mfma && block_size % 4 != 0;
+  if (unaligned && !env_u64("NGD_BOOT_UNALIGNED", 1)) return NGD_OK;
   if (n_blocks >= (1ull << 31)) return NGD_OK;
   // split large blocks so that there are enough workgroups; slices of one block share its weight
   const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
@@ -663,7 +673,8 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   } else {
     const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1)) : e->n_tiles16;
     const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
-    while (tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 && unit / (sub * 2) >= 32)
+    while (!unaligned && tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 &&
+           unit / (sub * 2) >= 32)
       sub *= 2;
     nks = n_blocks * sub;
     if (mfma) nks = (nks + 7) / 8 * 8;  // the XCD deal of accum_mfma.hip
@@ -710,6 +721,14 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     e->boot_nks = (uint32_t)nks;
     e->boot_sub = (uint32_t)sub;
     e->boot_per_slice = unit / sub;
+    if (unaligned) {
+      const uint32_t w_stride = (uint32_t)((3 * block_size + 3) / 4 + 1 + NGD_KG_TAIL);
+      rc = ensure_cap(e, &e->d_wslice, &e->cap_wslice, (uint64_t)e->boot_nks * w_stride * 4);
+      if (rc) return rc;
+      ngd_launch_slice_weights(e->st, e->boot_nks, w_stride, 3 * block_size, 3 * n_eff, e->d_wslice);
+      launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, 0, (3 * n_eff + 3) / 4, e->slab_boot, 3 * block_size,
+                        w_stride);
+    } else
     launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
     HIPCHK(hipGetLastError());
     e->boot_B = block_size;

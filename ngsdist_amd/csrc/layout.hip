@@ -166,6 +166,16 @@ __global__ void k_expand_batch(const uint32_t *__restrict__ mult, uint32_t n_rep
   }
 }
 
+// 0/1 weights per slice for bootstrap blocks that are not whole k-groups (accum_mfma.hip, k_per_slice)
+__global__ void k_slice_weights(uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total, double *W) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)n_slices * stride * 4) return;
+  const uint64_t slice = t / ((uint64_t)stride * 4), r = t % ((uint64_t)stride * 4);
+  const uint64_t k = (((slice * k_per_slice) >> 2) << 2) + r;
+  const uint64_t lo = slice * k_per_slice, hi = lo + k_per_slice < k_total ? lo + k_per_slice : k_total;
+  W[t] = (k >= lo && k < hi) ? 1.0 : 0.0;
+}
+
 // bit-planes of the per-site multiplicity, for weighted valid-site counts
 __global__ void k_planes(const uint32_t *__restrict__ ws, uint64_t n_sites, uint32_t n_words,
                          uint32_t n_planes, unsigned long long *planes) {
@@ -315,6 +325,14 @@ void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n
                               double *d_W) {
   hipLaunchKernelGGL(k_expand_batch, dim3((unsigned)((n_sites_alloc + 255) / 256)), dim3(256), 0, st, d_mult, n_rep, rb,
                      lead_full, n_blocks, block_size, n_sites, n_sites_alloc, d_W);
+}
+
+void ngd_launch_slice_weights(hipStream_t st, uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total,
+                              double *d_W) {
+  const uint64_t n = (uint64_t)n_slices * stride * 4;
+  if (!n) return;
+  hipLaunchKernelGGL(k_slice_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_slices, stride, k_per_slice,
+                     k_total, d_W);
 }
 
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,

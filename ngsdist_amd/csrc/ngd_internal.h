@@ -88,6 +88,10 @@ void ngd_launch_kg_compact(hipStream_t st, const double *d_wk, uint64_t n_kg, ui
 void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n_rep, uint32_t rb, int lead_full,
                               uint64_t n_blocks, uint64_t block_size, uint64_t n_sites, uint64_t n_sites_alloc,
                               double *d_W);
+// W[slice][j][c] = 1 if contraction index 4 (kg0(slice) + j) + c lies in [slice k_per_slice, (slice+1) k_per_slice)
+// and below k_total, else 0; kg0(slice) = slice * k_per_slice / 4; j < stride
+void ngd_launch_slice_weights(hipStream_t st, uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total,
+                              double *d_W);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 
@@ -97,11 +101,13 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
                              const uint64_t *d_pairs, uint64_t n_owned, double *d_sum);
 
 // accum_mfma.hip : FP64 MFMA tiles, split over site slices into slabs
-// d_wk / d_kgl: bootstrap weights per contraction index and the list of k-groups to visit (both or neither);
-// with a list, kg_per_slice and n_kg_eff count LIST entries
+// d_wk / d_kgl: bootstrap weights per contraction index and the list of k-groups to visit; with a list,
+// kg_per_slice and n_kg_eff count LIST entries.  k_per_slice != 0: slices are k_per_slice contraction indices
+// (not whole k-groups) and d_wk holds w_slice_stride k-groups of 0/1 weights PER SLICE (ngd_launch_slice_weights).
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_wk, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
-                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
+                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
+                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab);
 
 // accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
 void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,

@@ -148,7 +148,8 @@ def test_bootstrap_replicates(kernel, block_size):
         assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
-@pytest.mark.parametrize("kernel,block_size", [("mfma", 8), ("mfma", 100), ("em_fast", 5), ("em_faithful", 12)])
+@pytest.mark.parametrize("kernel,block_size", [("mfma", 8), ("mfma", 100), ("mfma", 7), ("mfma", 1), ("mfma", 10),
+                                               ("em_fast", 5), ("em_faithful", 12)])
 def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkeypatch):
     """Replicates served from per-block partial sums (default) vs. one weighted accumulation
     pass per replicate (NGD_BOOT_PARTIALS=0): same counts, sums within rounding, both within
