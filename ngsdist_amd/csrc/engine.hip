@@ -370,15 +370,16 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       // Workgroups all last the same, so an XCD works through its share (n_wg * ks / 8 workgroups) in rounds of
       // as many as it holds at a time, and a last round that is nearly empty costs as much as a full one
       // ([measured] cfg 3, 34 workgroups per slice: ks = 232 -> 10.27 rounds, 47.5 ms; 240 -> 10.63, 46.1 ms;
-      // 248 -> 10.98, 44.65 ms).  Among the slice counts within 15 % of the target take the one whose last
-      // round is fullest.
+      // 248 -> 10.98, 44.65 ms; cfg 2, 10 single-wavefront jobs per slice: 584 -> 1.90 rounds, 448 -> 1.46 rounds,
+      // 0.41 ms, 304 -> 0.99 rounds, 0.345 ms and half the slabs to reduce).  Among the slice counts from half the
+      // target to 15 % above it take the one whose last round is fullest.
       hipDeviceProp_t prop;
       const uint32_t cus_per_xcd = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8
                                        ? (uint32_t)prop.multiProcessorCount / 8 : 32;
       const double slots = (double)cus_per_xcd * (e->exact_shapes ? 12 : 3);
       double best = 1e30;
       uint64_t best_ks = ks;
-      for (uint64_t c = std::max<uint64_t>(8, ks * 85 / 100 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
+      for (uint64_t c = std::max<uint64_t>(8, ks / 2 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
         const double rounds = (double)wg_per_slice * (double)(c / 8) / slots;
         const double waste = std::ceil(rounds - 1e-9) / rounds + 1e-4 * std::fabs((double)c - (double)ks) / (double)ks;
         if (waste < best) { best = waste; best_ks = c; }
