@@ -42,4 +42,7 @@ def gather_matrices(all_t, mine_t):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         all_t[0].copy_(mine_t)
         return
-    dist.all_gather(list(all_t.unbind(0)), mine_t)
+    if dist.get_backend() == "nccl" and all_t.is_contiguous():
+        dist.all_gather_into_tensor(all_t, mine_t)  # RCCL's native all-gather into the [world][n_pairs] tensor
+    else:
+        dist.all_gather(list(all_t.unbind(0)), mine_t)
