@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)  # the first two launches after the fill run at a lower clock
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_fast", "em_faithful"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -100,7 +100,7 @@ def main():
     n_pairs = N.n_pairs(n_ind)
     kernel = args.kernel
     if kernel == "auto":
-        kernel = "mfma" if W["indep"] else "em_fast"
+        kernel = "mfma" if W["indep"] else "em_table"
 
     shard = args.shard
     if shard == "auto":

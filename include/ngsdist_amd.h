@@ -48,6 +48,7 @@ extern "C" {
 #define NGD_KERNEL_MFMA 2   /* indep: FP64 MFMA tiles over the (pair, site) contraction */
 #define NGD_KERNEL_EM_FAITHFUL 3 /* EM: iterates bit-identical to emOptim2.cpp */
 #define NGD_KERNEL_EM_FAST 4     /* EM: division-free power iteration, same stopping rule */
+#define NGD_KERNEL_EM_TABLE 5    /* EM: the fast form with per-individual tables shared by a 64x64 tile of pairs */
 
 typedef struct ngd_engine ngd_engine;
 

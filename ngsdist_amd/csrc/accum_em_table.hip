@@ -1,0 +1,373 @@
+// accum_em_table.hip -- gen_dist() without --indep_geno (reference ngsDist.cpp:340-353 around em2(),
+// emOptim2.cpp:112-135), tiled so that everything that depends on ONE individual is computed once per
+// tile and site instead of once per pair.
+//
+// For one site the EM iterate has a closed form (accum_em.hip): with a_k = GL1[x]*GL2[y],
+//   sfs_t = a^t / S_t,  S_t = SUM_k a_k^t = A_t(i1) * A_t(i2),  A_t(i) = SUM_x GL_i[x]^t   (rank one),
+//   lik_t = log(S_{t+1} / S_t),
+// and the stopping rule |lik_t - lik_{t-1}| < tole (emOptim2.cpp:127) reads
+//   R_t(i1) * R_t(i2) < e^tole,        R_t(i) = A_{t+1}(i) A_{t-1}(i) / A_t(i)^2   (>= 1),
+// the returned sfs being sfs_T for the first such t = T (or T = maxIter = 50), so that the site's score-weighted
+// sum (ngsDist.cpp:351-353) is
+//   c = f_T(i1)' * score * f_T(i2),    f_t(i) = GL_i^t / A_t(i).
+// R_t and f_t belong to ONE individual.  A workgroup owns a 64 x 64 tile of pairs and a slice of sites; per
+// site it builds the tables of the tile's 64 + 64 individuals in LDS, CH EM steps at a time:
+//   rows:    Q_t = e^tole / R_t  and f_t;        columns: R_t and g_t = score * f_t,
+// then every wavefront (lane = column, 64 / NW rows each) finds T of its pairs by comparing R_t(column) with
+// Q_t(row) -- one FP64 compare + one select per step and pair -- and adds f_T(row) . g_T(column).  Pairs
+// that have not stopped within the CH steps wait for the next CH (a second round is the rule, a third
+// rare; step 50 is forced).  Against the per-pair form (k_accum_em<fast>: ~16 FP64 instructions per
+// step and pair, 46 per pair-site at the end) this is 2 per step and ~10 per round at the end.
+//
+// Same arithmetic contract as the fast form: the stopping step is the reference's except where the
+// criterion is within rounding of the tolerance; sums agree to ~1e-13 relative (bar: 1e-9).
+// Missing sites under --pairwise_del (ngsDist.cpp:335-338) take Q = +inf / R = 0 and f = g = 0 at
+// every step: the pair stops at step 1 and adds exactly 0.
+#include "ngd_internal.h"
+
+namespace {
+
+constexpr int TS = 64;        // tile edge (individuals)
+constexpr int MAX_ITER = 50;  // ngsDist.cpp:349
+
+typedef double ngd_d2 __attribute__((ext_vector_type(2)));
+
+// LDS reads are written so that each becomes ONE ds_read_b64 / ds_read_b128: hipcc otherwise pairs 8-byte reads
+// into ds_read2_b64 / ds_read2st64_b64, which take 8 LDS cycles for the 16 bytes per lane that ds_read_b128 moves
+// in 4 and two ds_read_b64 in 2 + 2 (MI355X_MICROARCH.md, LDS table) -- and this kernel is bound by those cycles.
+// (volatile: the pairing pass leaves such reads alone; the address space is spelled out because a volatile access
+// through a generic pointer is not narrowed to LDS by the compiler)
+typedef __attribute__((address_space(3))) const volatile double ngd_lds_cvd;
+__device__ __forceinline__ double lds_b64(const double *p) { return *(ngd_lds_cvd *)p; }
+
+template <int CH>
+struct alignas(16) em_tables {
+  static constexpr int RS = CH + 2;  // row-table stride in doubles: spreads the builders' stores over the banks, 16-B aligned
+  double Qr[TS * RS];                // rows:    e^tole / R_t            [row][step]
+  double Fr[3][TS * RS];             // rows:    f_t[x]                  [x][row][step]
+  double Rc[CH * TS];                // columns: R_t                     [step][column]
+  double Gc[3][CH * TS];             // columns: (score * f_t)[x]        [x][step][column]
+  uint32_t more[2];                  // "some pair of the tile has not stopped yet", one word per round parity
+};
+
+// Workgroup barrier that waits for this wavefront's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the
+// global loads of the NEXT site's likelihoods that are meant to stay in flight across the rounds of this one
+// ([measured] 1000 x 2e4: 51.5 ms with __syncthreads(), the loads' latency exposed once per site and workgroup).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Four steps of the search for a pair's stopping step T, the lanes that have stopped dropping out of EXEC:
+//   for each step: EXEC &= !(R < Q);  n += 1 in the lanes still active
+// so n counts the steps a lane has NOT stopped at (two VALU instructions per step: the compare writes EXEC, nothing
+// reads a compare result as a select mask, which would cost a third instruction and two wait states per step).
+// m: in = lanes still searching, out = those that have not stopped within these steps either.  EXEC is restored.
+__device__ __forceinline__ void scan4(uint64_t &m, uint32_t &n, double r0, double r1, double r2, double r3, double q0,
+                                      double q1, double q2, double q3) {
+  uint64_t keep;
+  asm volatile(
+      "s_mov_b64 %[keep], exec\n\t"
+      "s_and_b64 exec, exec, %[m]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r0], %[q0]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r1], %[q1]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r2], %[q2]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r3], %[q3]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "s_mov_b64 %[m], exec\n\t"
+      "s_mov_b64 exec, %[keep]"
+      : [m] "+s"(m), [n] "+v"(n), [keep] "=&s"(keep)
+      : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3)
+      : "vcc");
+}
+
+__device__ __forceinline__ double rcp_nr(double a) {
+  double y = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-a, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+
+// One wavefront's share of a table round: steps tfirst+1 .. tfirst+SEG of its 64 individuals (lane = individual),
+// v = GL^tfirst.  One role per call, so that the whole share is one block of straight-line code: the SEG+2 power
+// sums and their reciprocals are independent of each other and the scheduler can keep the FP64 pipe full.
+template <int CH, int SEG, bool ROW>
+__device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, const double *g, const ngd_score &sc,
+                                            uint32_t lane, uint32_t seg, int tfirst, bool miss) {
+  constexpr int RS = em_tables<CH>::RS;
+  const double E = 0x1.0041919b7ee34p+0;  // exp(0.001), the tolerance of ngsDist.cpp:349
+  // pw[k] = GL^(tfirst+k), A[k] its sum, r[k] = 1/A[k]; k = 1 .. SEG are the steps written
+  double pw[SEG + 2][3], A[SEG + 2], r[SEG + 2];
+#pragma unroll
+  for (int x = 0; x < 3; x++) pw[0][x] = v[x];
+#pragma unroll
+  for (int k = 1; k < SEG + 2; k++)
+#pragma unroll
+    for (int x = 0; x < 3; x++) pw[k][x] = pw[k - 1][x] * g[x];
+#pragma unroll
+  for (int k = 0; k < SEG + 2; k++) A[k] = (pw[k][0] + pw[k][1]) + pw[k][2];
+#pragma unroll
+  for (int k = 0; k < SEG + 2; k++) r[k] = rcp_nr(A[k]);
+#pragma unroll
+  for (int k = 1; k <= SEG; k++) {
+    const uint32_t tt = seg * SEG + k - 1;
+    const bool force = miss || tfirst + k >= MAX_ITER;
+    double f[3];
+#pragma unroll
+    for (int x = 0; x < 3; x++) f[x] = miss ? 0.0 : pw[k][x] * r[k];
+    if (ROW) {
+      double q = (E * (A[k] * A[k])) * (r[k + 1] * r[k - 1]);
+      if (force) q = __builtin_inf();
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 3  // timing experiment: tables computed, not stored
+      asm volatile("" ::"v"(q), "v"(f[0]), "v"(f[1]), "v"(f[2]));
+      if (tfirst < 0)
+#endif
+      {
+      L.Qr[lane * RS + tt] = q;
+#pragma unroll
+      for (int x = 0; x < 3; x++) L.Fr[x][lane * RS + tt] = f[x];
+      }
+    } else {
+      double rr = (A[k + 1] * A[k - 1]) * (r[k] * r[k]);
+      if (force) rr = 0.0;
+      double gg[3];
+#pragma unroll
+      for (int x = 0; x < 3; x++)
+        gg[x] = __builtin_fma(sc.v[3 * x + 2], f[2], __builtin_fma(sc.v[3 * x + 1], f[1], sc.v[3 * x] * f[0]));
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 3
+      asm volatile("" ::"v"(rr), "v"(gg[0]), "v"(gg[1]), "v"(gg[2]));
+      if (tfirst < 0)
+#endif
+      {
+      L.Rc[tt * TS + lane] = rr;
+#pragma unroll
+      for (int x = 0; x < 3; x++) L.Gc[x][tt * TS + lane] = gg[x];
+      }
+    }
+  }
+}
+
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5  // diagnostic build: where a wavefront's cycles go (tools/em_stamps.py)
+#define EMT_STAMP(slot)                                                              \
+  do {                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    unsigned long long _t;                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    stamp_sum[slot] += (double)(_t - stamp_last);                                    \
+    stamp_last = _t;                                                                 \
+  } while (0)
+#else
+#define EMT_STAMP(slot) do { } while (0)
+#endif
+
+// NW wavefronts per workgroup (64 / NW rows each), CH steps per table round, WPS = waves per SIMD the
+// register allocation is held to (workgroups per CU x NW / 4)
+template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL>
+__global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
+    const double *__restrict__ PA, const uint32_t *__restrict__ ws, ngd_score sc, const ngd_tile *__restrict__ tiles,
+    uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind, uint64_t n_sites_eff, uint64_t sites_per_slice,
+    double *__restrict__ slab) {
+  constexpr int RPW = TS / NW;  // rows per wavefront
+  constexpr int RS = em_tables<CH>::RS;
+  // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
+  constexpr int GR = WPS >= 4 ? 1 : 4;
+  static_assert(RPW % GR == 0 && CH % 4 == 0, "shape");
+  __shared__ em_tables<CH> L;
+  const uint32_t tile = blockIdx.x % n_tiles;
+  const uint32_t ks = blockIdx.x / n_tiles;
+  const uint32_t I0 = tiles[tile].ti * TS, J0 = tiles[tile].tj * TS;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint64_t s0 = (uint64_t)ks * sites_per_slice;
+  uint64_t s1 = s0 + sites_per_slice;
+  if (s1 > n_sites_eff) s1 = n_sites_eff;
+
+  // scanning role: lane = column, rows wave*RPW .. +RPW-1
+  const uint32_t j = J0 + lane;
+  uint32_t live = 0;  // bit r: pair (I0 + wave*RPW + r, j) exists
+#pragma unroll
+  for (int r = 0; r < RPW; r++)
+    if (I0 + wave * RPW + r < j && j < n_ind) live |= 1u << r;
+  double acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; r++) acc[r] = 0;
+
+  // building role: every wavefront builds.  Wavefronts 0 .. NW/2-1 own the tile's rows, the others its columns
+  // (lane = individual); wavefront p of a role writes steps p*SEG+1 .. (p+1)*SEG of each round, so a round's CH steps
+  // are SEG dependent multiplications deep instead of CH.  All of it is wave-uniform control flow.
+  constexpr int NP = NW / 2;     // wavefronts per role
+  constexpr int SEG = CH / NP;   // steps per wavefront and round
+  static_assert(CH % NP == 0, "shape");
+  const bool is_row = wave < NP;
+  const uint32_t seg = is_row ? wave : wave - NP;
+  const uint32_t bind = (is_row ? I0 : J0) + lane;
+  const double *pb = PA + (uint64_t)(bind >> 4) * 64 + (bind & 15);
+  const uint64_t kstride = (uint64_t)n_ig * 64;  // doubles between consecutive k-groups
+  auto load_site = [&](uint64_t s, double *g) {
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 4  // timing experiment: no global loads
+    g[0] = 0.5 + 0.001 * (double)((s + lane) & 63); g[1] = 0.3; g[2] = 0.2 - 0.001 * (double)((s + lane) & 63);
+    return;
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const uint64_t k = 3 * s + c;
+      g[c] = pb[(k >> 2) * kstride + (k & 3) * 16];
+    }
+  };
+  double gn[3] = {0, 0, 0};
+  if (s0 < s1) load_site(s0, gn);
+  if (tid < 2) L.more[tid] = 0;
+  uint32_t round = 0;  // table rounds so far (all sites): parity selects the flag word
+
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+  double stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+  for (uint64_t s = s0; s < s1; s++) {
+    double wgt = 1.0;
+    EMT_STAMP(0);  // loop overhead, end-of-site
+    double g[3] = {gn[0], gn[1], gn[2]};
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+    asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]));  // the wait for the loads happens here
+    EMT_STAMP(1);  // waiting for this site's likelihoods
+#endif
+    if (s + 1 < s1) load_site(s + 1, gn);  // in flight while this site is worked on
+    if (WEIGHTED) {
+      const uint32_t m = ws[s];
+      if (m == 0) continue;  // site not drawn in this replicate (uniform across the workgroup)
+      wgt = (double)m;
+    }
+    // v = g^(t0 + seg*SEG): the power one step before this wavefront's first step of the round; gch = g^CH
+    double v[3] = {1.0, 1.0, 1.0}, gch[3];
+    {
+      double sq[3] = {g[0], g[1], g[2]};  // g^(2^b)
+#pragma unroll
+      for (int bit = 0; (1 << bit) <= CH; bit++) {
+        if ((seg * SEG) >> bit & 1) {
+#pragma unroll
+          for (int x = 0; x < 3; x++) v[x] *= sq[x];
+        }
+        if (CH >> bit & 1) {  // compile time: CH = 16 -> g^16, CH = 12 -> g^8 * g^4
+#pragma unroll
+          for (int x = 0; x < 3; x++) gch[x] = (CH & ((1 << bit) - 1)) ? gch[x] * sq[x] : sq[x];
+        }
+#pragma unroll
+        for (int x = 0; x < 3; x++) sq[x] *= sq[x];
+      }
+    }
+    const bool miss = PDEL && ngd_miss(g[0], g[1], g[2]);
+    uint32_t todo = live;
+    EMT_STAMP(2);  // per-site set-up (powers)
+    // (every pair has stopped by step MAX_ITER, where the tables force it: the bound only restates that)
+    for (int t0 = 0; t0 < MAX_ITER; t0 += CH, round++) {  // steps t0+1 .. t0+CH
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 1  // timing experiment: tables built for the slice's first site only
+      if (s == s0)
+#endif
+      {
+        const int tfirst = t0 + (int)seg * SEG;  // this wavefront's steps are tfirst+1 .. tfirst+SEG
+        if (is_row) build_round<CH, SEG, true>(L, v, g, sc, lane, seg, tfirst, miss);
+        else build_round<CH, SEG, false>(L, v, g, sc, lane, seg, tfirst, miss);
+#pragma unroll
+        for (int x = 0; x < 3; x++) v[x] *= gch[x];
+      }
+      EMT_STAMP(3);  // building
+      wg_barrier();
+      EMT_STAMP(4);  // barrier after building
+      // the other parity's word: every wavefront has read it (it is behind that read), it is next written after the
+      // next round's first barrier
+      if (tid == 0) L.more[(round & 1) ^ 1] = 0;
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 2  // timing experiment: no scan, two rounds per site
+      if (t0 >= CH) todo = 0;
+      if (false) {
+#else
+      if (__builtin_amdgcn_ballot_w64(todo != 0)) {
+#endif
+        double R2[CH];
+#pragma unroll
+        for (int tt = 0; tt < CH; tt++) R2[tt] = lds_b64(&L.Rc[tt * TS + lane]);
+#pragma unroll
+        for (int gr = 0; gr < RPW / GR; gr++) {
+          const uint32_t gmask = ((1u << GR) - 1) << (gr * GR);
+          if (__builtin_amdgcn_ballot_w64((todo & gmask) != 0) == 0) continue;  // these rows are finished in every lane
+          int T[GR];
+#pragma unroll
+          for (int q = 0; q < GR; q++) {
+            const uint32_t rb = (wave * RPW + gr * GR + q) * RS;
+            ngd_d2 Q[CH / 2];  // the row's CH thresholds: the same 16 bytes in every lane, one ds_read_b128 per two steps
+#pragma unroll
+            for (int h = 0; h < CH / 2; h++) Q[h] = *(const ngd_d2 *)&L.Qr[rb + 2 * h];
+            const bool mine = (todo >> (gr * GR + q)) & 1;
+            uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+            uint32_t n = 0;
+#pragma unroll
+            for (int b = 0; b < CH / 4; b++) {
+              if (b && m == 0) break;  // every lane has stopped
+              scan4(m, n, R2[4 * b], R2[4 * b + 1], R2[4 * b + 2], R2[4 * b + 3], Q[2 * b][0], Q[2 * b][1], Q[2 * b + 1][0],
+                    Q[2 * b + 1][1]);
+            }
+            T[q] = mine && n < (uint32_t)CH ? (int)n + 1 : 0;
+          }
+#pragma unroll
+          for (int q = 0; q < GR; q++) {
+            const int r = gr * GR + q;
+            const uint32_t ti = T[q] ? T[q] - 1 : 0;
+            const uint32_t a = (wave * RPW + r) * RS + ti, b = ti * TS + lane;
+            double c = lds_b64(&L.Fr[0][a]) * lds_b64(&L.Gc[0][b]);
+            c = __builtin_fma(lds_b64(&L.Fr[1][a]), lds_b64(&L.Gc[1][b]), c);
+            c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
+            if (WEIGHTED) c = c * wgt;
+            if (T[q]) {
+              acc[r] = acc[r] + c;
+              todo &= ~(1u << r);
+            }
+          }
+        }
+      }
+      EMT_STAMP(5);  // scanning
+      const bool left = __builtin_amdgcn_ballot_w64(todo != 0) != 0;
+      if (left && lane == 0) L.more[round & 1] = 1;
+      wg_barrier();  // also the barrier that lets the next round overwrite the tables
+      EMT_STAMP(6);  // barrier after scanning
+      if (*(const volatile __attribute__((address_space(3))) uint32_t *)&L.more[round & 1] == 0) { round++; break; }
+    }
+  }
+#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+#pragma unroll
+  for (int r = 0; r < RPW && r < 8; r++) acc[r] = stamp_sum[r];
+#endif
+#pragma unroll
+  for (int r = 0; r < RPW; r++)
+    slab[((uint64_t)ks * n_pad + (I0 + wave * RPW + r)) * n_pad + j] = acc[r];
+}
+
+}  // namespace
+
+// shape: 0 = 8 wavefronts x 8 rows, 16 steps per round, 4 waves per SIMD (default: [measured] 1000 x 2e4, ms per launch:
+//            51.1; shape 1: 61.2; 2: 54.0; 3: 67.1; k_accum_em<fast> 122.7);
+//        1 = 4 wavefronts x 16 rows, 16 steps, 2 waves per SIMD (register-rich);  2 / 3 = the same two with 12 steps
+void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
+                               uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
+                               const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
+                               double *slab) {
+  if (!n_tiles64) return;
+  const bool w = d_ws != nullptr, p = pairwise_del != 0;
+#define NGD_EMT(NW, CH, WPS, W, P)                                                                              \
+  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
+                     score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab)
+#define NGD_EMT_WP(NW, CH, WPS)                                              \
+  do {                                                                       \
+    if (w) { if (p) NGD_EMT(NW, CH, WPS, true, true); else NGD_EMT(NW, CH, WPS, true, false); }   \
+    else   { if (p) NGD_EMT(NW, CH, WPS, false, true); else NGD_EMT(NW, CH, WPS, false, false); } \
+  } while (0)
+  switch (shape) {
+    default: NGD_EMT_WP(8, 16, 4); break;
+    case 1: NGD_EMT_WP(4, 16, 2); break;
+    case 2: NGD_EMT_WP(8, 12, 4); break;
+    case 3: NGD_EMT_WP(4, 12, 2); break;
+  }
+#undef NGD_EMT_WP
+#undef NGD_EMT
+}

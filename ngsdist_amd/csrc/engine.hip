@@ -48,8 +48,9 @@ struct ngd_engine {
   uint64_t cap_h_mult = 0;
   uint64_t cap_blocks = 0;
   // shard
-  ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr;
-  uint32_t n_tiles = 0, n_tiles16 = 0;
+  ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr, *d_tiles64 = nullptr;
+  uint32_t n_tiles = 0, n_tiles16 = 0, n_tiles64 = 0;
+  int em_shape = 0;  // accum_em_table.hip: workgroup shape
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
   ngd_job *d_jobs = nullptr;
   uint32_t n_wg = 0;
@@ -159,7 +160,7 @@ void ngd_destroy(ngd_engine *e) {
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
-                  e->d_tiles, e->d_tiles16, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
+                  e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -201,8 +202,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     if (kernel != NGD_KERNEL_MFMA && kernel != NGD_KERNEL_STREAM)
       return fail(NGD_E_INVALID, "ngd_create: kernel does not serve --indep_geno");
   } else {
-    if (kernel == NGD_KERNEL_AUTO) kernel = NGD_KERNEL_EM_FAST;
-    if (kernel != NGD_KERNEL_EM_FAST && kernel != NGD_KERNEL_EM_FAITHFUL)
+    if (kernel == NGD_KERNEL_AUTO) kernel = NGD_KERNEL_EM_TABLE;
+    if (kernel != NGD_KERNEL_EM_FAST && kernel != NGD_KERNEL_EM_FAITHFUL && kernel != NGD_KERNEL_EM_TABLE)
       return fail(NGD_E_INVALID, "ngd_create: kernel does not serve the EM path");
   }
 
@@ -237,7 +238,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     if (hipEventCreate(&v) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: hipEventCreate failed"));
 
   // ---- shard: upper-triangular 128-tiles dealt by cost over ranks (ngd_shard.h) ----
-  std::vector<ngd_tile> tiles, tiles16;
+  std::vector<ngd_tile> tiles, tiles16, tiles64;
   std::vector<uint64_t> pairs;
   const std::vector<uint32_t> owner = ngd_tile_owners(g.n_t, world);
   uint32_t tid = 0;
@@ -245,6 +246,12 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     for (uint32_t tj = ti; tj < g.n_t; tj++, tid++) {
       if (owner[tid] != cfg->shard_rank) continue;
       tiles.push_back({(uint16_t)ti, (uint16_t)tj});
+      for (uint32_t a = 0; a < 2; a++)  // 64 x 64 tiles of the table-driven EM kernel
+        for (uint32_t b = 0; b < 2; b++) {
+          const uint32_t i64 = 2 * ti + a, j64 = 2 * tj + b;
+          if (i64 > j64 || (uint64_t)i64 * 64 >= g.n_ind || (uint64_t)j64 * 64 >= g.n_ind) continue;
+          tiles64.push_back({(uint16_t)i64, (uint16_t)j64});
+        }
       for (uint32_t a = 0; a < NGD_IG_PER_TILE; a++)
         for (uint32_t b = 0; b < NGD_IG_PER_TILE; b++) {
           uint32_t ig = ti * NGD_IG_PER_TILE + a, jg = tj * NGD_IG_PER_TILE + b;
@@ -255,6 +262,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     }
   e->n_tiles = (uint32_t)tiles.size();
   e->n_tiles16 = (uint32_t)tiles16.size();
+  e->n_tiles64 = (uint32_t)tiles64.size();
   // job list of the MFMA kernel (ngd_job, units of 16 individuals).
   std::vector<ngd_job> jobs;
   const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);  // groups that hold at least one individual
@@ -326,6 +334,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } while (0)
   TRY(dev_alloc(e, &e->d_tiles, tiles.size(), false));
   TRY(dev_alloc(e, &e->d_tiles16, tiles16.size(), false));
+  TRY(dev_alloc(e, &e->d_tiles64, tiles64.size(), false));
   TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
   TRY(dev_alloc(e, &e->d_jobs, jobs.size(), false));
   if (!jobs.empty())
@@ -337,6 +346,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
   if (!tiles16.empty())
     if (hipMemcpy(e->d_tiles16, tiles16.data(), tiles16.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
+  if (!tiles64.empty())
+    if (hipMemcpy(e->d_tiles64, tiles64.data(), tiles64.size() * sizeof(ngd_tile), hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(NGD_E_HIP, "ngd_create: tile list upload failed"));
   if (!pairs.empty())
     if (hipMemcpy(e->d_pairs, pairs.data(), pairs.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)
@@ -391,6 +403,18 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+  } else if (kernel == NGD_KERNEL_EM_TABLE) {
+    // 64 x 64 tiles x slices of sites; a workgroup works a site in ~10 us, so slices of a few thousand sites keep
+    // the tail of the launch short without making the slab large
+    e->em_shape = (int)env_u64("NGD_EMT_SHAPE", 0);
+    uint64_t want = env_u64("NGD_EMT_WG", 16384);
+    uint64_t ks = e->n_tiles64 ? (want + e->n_tiles64 - 1) / e->n_tiles64 : 1;
+    uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 64);
+    ks = std::min(ks, max_ks);
+    ks = std::max<uint64_t>(1, env_u64("NGD_EM_KS", ks));
+    e->n_ks = (uint32_t)ks;
+    e->per_slice = (g.n_sites + ks - 1) / ks;
+    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
   } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
     uint64_t want = env_u64("NGD_EM_WG", 4096);
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
@@ -556,6 +580,10 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
                               (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
                               kg_lim, k_per_slice, w_stride, slab);
       break;
+    case NGD_KERNEL_EM_TABLE:
+      ngd_launch_accum_em_table(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del, e->em_shape, e->d_tiles64,
+                                e->n_tiles64, n_ks, per_slice, slab);
+      break;
     default:
       ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
                           e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
@@ -672,7 +700,8 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     sub = e->boot_sub;
     nks = e->boot_nks;
   } else {
-    const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1)) : e->n_tiles16;
+    const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1))
+                                  : e->kernel == NGD_KERNEL_EM_TABLE ? e->n_tiles64 : e->n_tiles16;
     const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
     while (!unaligned && tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 &&
            unit / (sub * 2) >= 32)
@@ -699,7 +728,8 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
       // what this call costs without the partials: a list-driven pass per replicate (MFMA, ~3/4 of a pass)
       // or a batch pass per 16 replicates (EM); rates are the measured ones of DESIGN.md section 6
       const double ps = (double)e->n_owned_pairs * (double)n_eff;
-      const double pass_ms = mfma ? ps / 1.05e10 : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
+      const double pass_ms = mfma ? ps / 1.05e10 : e->kernel == NGD_KERNEL_EM_TABLE ? ps / 3e8
+                             : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
       const double alt_ms = mfma ? 0.75 * pass_ms * n_rep : 1.1 * pass_ms * ((n_rep + 15) / 16);
       if (e->rent_B != block_size || e->rent_blocks != n_blocks) {
         e->rent_B = block_size; e->rent_blocks = n_blocks; e->rent_ms = 0;

@@ -20,7 +20,7 @@
 //  * a file name without a '.' is treated as binary instead of dereferencing
 //    NULL (ngsDist.cpp:82);
 //  * extra options: --n_gpus N (pair tiles dealt over N devices of this node),
-//    --device D (first device), --kernel auto|stream|mfma|em_fast|em_faithful,
+//    --device D (first device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful,
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -151,6 +151,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
         else if (!strcmp(optarg, "mfma")) p.kernel = NGD_KERNEL_MFMA;
         else if (!strcmp(optarg, "em_fast")) p.kernel = NGD_KERNEL_EM_FAST;
         else if (!strcmp(optarg, "em_faithful")) p.kernel = NGD_KERNEL_EM_FAITHFUL;
+        else if (!strcmp(optarg, "em_table")) p.kernel = NGD_KERNEL_EM_TABLE;
         else die(__FUNCTION__, "unknown --kernel");
         break;
       case 1004:

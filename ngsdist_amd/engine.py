@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 
-KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4}
+KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4, "em_table": 5}
 
 # parse_args.cpp:25-27
 DEFAULT_SCORE = (0.0, 0.5, 1.0, 0.5, 0.0, 0.5, 1.0, 0.5, 0.0)

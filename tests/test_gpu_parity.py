@@ -46,7 +46,7 @@ def gpu_pairs(p, kernel, pairwise_del=False, indep_geno=True, score=None, block_
 
 
 INDEP_KERNELS = ["stream", "mfma"]
-EM_KERNELS = ["em_faithful", "em_fast"]
+EM_KERNELS = ["em_faithful", "em_fast", "em_table"]
 
 
 @pytest.mark.parametrize("kernel", INDEP_KERNELS)
@@ -113,7 +113,8 @@ def test_golden_em(kernel):
 
 
 @pytest.mark.parametrize("kernel", EM_KERNELS)
-@pytest.mark.parametrize("n_ind,n_sites,miss", [(2, 1, 0.0), (6, 200, 0.0), (33, 700, 0.1), (20, 5000, 0.0)])
+@pytest.mark.parametrize("n_ind,n_sites,miss", [(2, 1, 0.0), (6, 200, 0.0), (33, 700, 0.1), (20, 5000, 0.0),
+                                                (65, 300, 0.05), (130, 257, 0.0)])
 def test_em(kernel, n_ind, n_sites, miss):
     p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=miss)
     for pd in (False, True):
@@ -149,7 +150,7 @@ def test_bootstrap_replicates(kernel, block_size):
 
 
 @pytest.mark.parametrize("kernel,block_size", [("mfma", 8), ("mfma", 100), ("mfma", 7), ("mfma", 1), ("mfma", 10),
-                                               ("em_fast", 5), ("em_faithful", 12)])
+                                               ("em_fast", 5), ("em_faithful", 12), ("em_table", 5), ("em_table", 32)])
 def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkeypatch):
     """Replicates served from per-block partial sums (default) vs. one weighted accumulation
     pass per replicate (NGD_BOOT_PARTIALS=0): same counts, sums within rounding, both within
@@ -182,7 +183,8 @@ def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkey
 
 @pytest.mark.parametrize("kernel,block_size,pdel", [("mfma", 8, True), ("mfma", 100, False), ("mfma", 7, True),
                                                     ("stream", 10, True), ("em_fast", 5, True),
-                                                    ("em_faithful", 12, False)])
+                                                    ("em_faithful", 12, False), ("em_table", 5, True),
+                                                    ("em_table", 1, False)])
 @pytest.mark.parametrize("n_rep", [1, 3, 21, 37])
 def test_bootstrap_batch(kernel, block_size, pdel, n_rep):
     """ngd_run_batch: n_rep replicates in one call == the same replicates one ngd_run at a time (identical
@@ -233,7 +235,8 @@ def test_bootstrap_batch_called_genotypes_bit_exact():
 @pytest.mark.parametrize("kernel,block_size,pdel,partials", [
     ("mfma", 8, True, True), ("mfma", 7, False, True), ("mfma", 1, True, True), ("stream", 3, False, True),
     ("em_fast", 5, True, True), ("em_fast", 1, True, False), ("em_fast", 7, False, False),
-    ("em_faithful", 3, True, False), ("em_faithful", 12, False, True)])
+    ("em_faithful", 3, True, False), ("em_faithful", 12, False, True),
+    ("em_table", 5, True, True), ("em_table", 1, True, False), ("em_table", 7, False, False)])
 @pytest.mark.parametrize("n_rep", [0, 1, 5, 20])
 def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep, monkeypatch):
     """ngd_run_job: matrix 0 = ngd_run(NULL) (counts exact, sums to rounding; bit-identical where the plan keeps the
