@@ -38,6 +38,10 @@ BYTES_PER_PAIR_SITE = 48.0  # stream model: two 3-double GL vectors per pair-sit
 FLOPS_PER_PAIR_SITE = 6.0   # tiled model: 3 FP64 FMA per pair-site (P . Q^T, K = 3*n_sites)
 PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (SURVEY 8d hardware constants)
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+# EM path, VALU lane-instructions counted in the ISA of the shipped kernels
+EMT_OPS_PER_SITE = 5.4      # k_accum_em_table: per-site set-up, per pair
+EMT_OPS_PER_ROUND = 65.6    # ... per pair and table round of 16 EM steps (scan + finalise 52.6, table build 13.0)
+EMFAST_OPS_PER_PAIR_SITE = 272.0  # k_accum_em<fast>: SQ_THREAD_CYCLES_VALU per pair-site, profiles/r01_cfg4_em_pmc.md
 
 WORKLOADS = {
     # BASELINE.json configs[1..4]
@@ -369,10 +373,34 @@ def main():
         if kernel == "stream":
             roof = dict(roof["stream_model"], kernel="k_accum_stream", traffic=None, ms_per_launch=acc_mean_ms)
     else:
-        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
-                "pair_sites_per_s": pair_sites_per_launch_all / world / t_acc,
-                "algorithmic": "FP64 VALU bound; flops are data dependent (EM iterations per site)"}
+        # EM path: bound by FP64 VALU issue (HBM is irrelevant: 48 B per ~130 instructions).  The roof is the FP64 vector
+        # pipe, 78.6 TFLOP/s = 39.3e12 lane-instruction slots/s x 2 flop (the same datapath and peak as FP64 MFMA,
+        # profiles/r01_fp64_peak_microbench.txt).  Algorithmic work = VALU lane-instructions per pair-site, counted in
+        # the ISA: the data-dependent factor is the number of EM steps, which the table kernel
+        # reports as table rounds per (tile, site) and which is fixed at its measured mean for the per-pair kernels.
+        ps_launch = pair_sites_per_launch_all / world
+        if kernel == "em_table":
+            tile_sites, rounds = eng.em_work()
+            rounds_per_site = rounds / max(1, tile_sites)
+            ops = EMT_OPS_PER_SITE + rounds_per_site * EMT_OPS_PER_ROUND
+            how = ("%.1f + %.3f table rounds per (tile, site) x %.1f VALU lane-instructions per pair-site (ISA count of "
+                   "k_accum_em_table: scan 52.6 + table build 13.0 per pair and round, 5.4 per site)"
+                   % (EMT_OPS_PER_SITE, rounds_per_site, EMT_OPS_PER_ROUND))
+        elif kernel == "em_fast":
+            ops, how = EMFAST_OPS_PER_PAIR_SITE, ("%.0f VALU lane-instructions per pair-site (k_accum_em<fast> at the mean "
+                                                  "11.7 EM steps of this data set, profiles/r01_cfg4_em_pmc.md)"
+                                                  % EMFAST_OPS_PER_PAIR_SITE)
+        else:
+            ops, how = None, "bit-faithful form: divides and log per step; no operation count kept"
+        ach = ops * ps_launch / t_acc * 2 / 1e12 if ops else None
+        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": ach, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS if ach else None, "traffic": None,
+                "ms_per_launch": acc_mean_ms, "pair_sites_per_s": ps_launch / t_acc,
+                "algorithmic": "FP64 vector issue (shares the FP64 MFMA datapath and its 78.6 TFLOP/s); 1 lane-instruction "
+                               "= 1 FMA slot = 2 flop; " + how}
+        if ops:  # the same launch priced with the per-pair algorithm's count (round 1's kernel): > 1 means work removed
+            roof["per_pair_model"] = {"lane_instructions_per_pair_site": EMFAST_OPS_PER_PAIR_SITE,
+                                      "frac": EMFAST_OPS_PER_PAIR_SITE * ps_launch / t_acc * 2 / 1e12 / PEAK_FP64_TFLOPS}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
     # figure is the one the last tools/profile.sh run of this same command left in profiles/

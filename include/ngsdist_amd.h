@@ -208,6 +208,10 @@ int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep
 int ngd_drop_caches(ngd_engine *e);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
+/* Work done by the table-driven EM kernel (NGD_KERNEL_EM_TABLE) in the last run, for roofline accounting: the number
+ * of (64 x 64 pair tile, site) visits and of table rounds (16 EM steps of a tile's 128 individuals each) -- the
+ * data-dependent part of its operation count (the EM's iteration count, emOptim2.cpp:118-133).  Zero for other kernels. */
+int ngd_last_em_work(const ngd_engine *e, uint64_t *tile_sites, uint64_t *table_rounds);
 
 /* The tail of gen_dist(), ngsDist.cpp:372-401, on the HOST with the host's
  * libm so that -0.0 / inf / nan cells print exactly as the reference's do:

@@ -168,7 +168,7 @@ template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL>
 __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     const double *__restrict__ PA, const uint32_t *__restrict__ ws, ngd_score sc, const ngd_tile *__restrict__ tiles,
     uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind, uint64_t n_sites_eff, uint64_t sites_per_slice,
-    double *__restrict__ slab) {
+    double *__restrict__ slab, unsigned long long *__restrict__ counters) {
   constexpr int RPW = TS / NW;  // rows per wavefront
   constexpr int RS = em_tables<CH>::RS;
   // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   if (s0 < s1) load_site(s0, gn);
   if (tid < 2) L.more[tid] = 0;
   uint32_t round = 0;  // table rounds so far (all sites): parity selects the flag word
+  uint32_t sites_done = 0;
 
 #if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
   double stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     }
     const bool miss = PDEL && ngd_miss(g[0], g[1], g[2]);
     uint32_t todo = live;
+    sites_done++;
     EMT_STAMP(2);  // per-site set-up (powers)
     // (every pair has stopped by step MAX_ITER, where the tables force it: the bound only restates that)
     for (int t0 = 0; t0 < MAX_ITER; t0 += CH, round++) {  // steps t0+1 .. t0+CH
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       if (*(const volatile __attribute__((address_space(3))) uint32_t *)&L.more[round & 1] == 0) { round++; break; }
     }
   }
+  if (tid == 0) {  // work done, for the roofline accounting of bench.py: (tile, site) visits and table rounds
+    atomicAdd(&counters[0], (unsigned long long)sites_done);
+    atomicAdd(&counters[1], (unsigned long long)round);
+  }
 #if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
 #pragma unroll
   for (int r = 0; r < RPW && r < 8; r++) acc[r] = stamp_sum[r];
@@ -351,12 +357,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
                                const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
-                               double *slab) {
+                               double *slab, unsigned long long *d_counters) {
   if (!n_tiles64) return;
   const bool w = d_ws != nullptr, p = pairwise_del != 0;
 #define NGD_EMT(NW, CH, WPS, W, P)                                                                              \
   hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
-                     score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab)
+                     score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab, d_counters)
 #define NGD_EMT_WP(NW, CH, WPS)                                              \
   do {                                                                       \
     if (w) { if (p) NGD_EMT(NW, CH, WPS, true, true); else NGD_EMT(NW, CH, WPS, true, false); }   \

@@ -51,6 +51,8 @@ struct ngd_engine {
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr, *d_tiles64 = nullptr;
   uint32_t n_tiles = 0, n_tiles16 = 0, n_tiles64 = 0;
   int em_shape = 0;  // accum_em_table.hip: workgroup shape
+  unsigned long long *d_emcnt = nullptr;  // [2] work counters of the table-driven EM kernel
+  unsigned long long em_counts[2] = {0, 0};  // ... of the last run
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
   ngd_job *d_jobs = nullptr;
   uint32_t n_wg = 0;
@@ -161,7 +163,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -415,6 +417,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
+    TRY(dev_alloc(e, &e->d_emcnt, 2, true));
   } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
     uint64_t want = env_u64("NGD_EM_WG", 4096);
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
@@ -582,7 +585,7 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
       break;
     case NGD_KERNEL_EM_TABLE:
       ngd_launch_accum_em_table(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del, e->em_shape, e->d_tiles64,
-                                e->n_tiles64, n_ks, per_slice, slab);
+                                e->n_tiles64, n_ks, per_slice, slab, e->d_emcnt);
       break;
     default:
       ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
@@ -591,6 +594,14 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
 }
 
 static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool add) {
+  if (e->d_emcnt) {  // the stream is idle: counters of the pass(es) since the last read
+    unsigned long long c[2] = {0, 0};
+    if (hipMemcpy(c, e->d_emcnt, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (!add) e->em_counts[0] = e->em_counts[1] = 0;
+      e->em_counts[0] += c[0]; e->em_counts[1] += c[1];
+      hipMemsetAsync(e->d_emcnt, 0, sizeof(c), e->st);
+    }
+  }
   float ms[4] = {0, 0, 0, 0};
   hipEventElapsedTime(&ms[0], e->ev[0], e->ev[4]);
   hipEventElapsedTime(&ms[1], e->ev[1], e->ev[2]);
@@ -1087,6 +1098,13 @@ int ngd_drop_caches(ngd_engine *e) {
   e->boot_blocks = 0;
   e->cnt_B = 0;
   e->cnt_blocks = 0;
+  return NGD_OK;
+}
+
+int ngd_last_em_work(const ngd_engine *e, uint64_t *tile_sites, uint64_t *table_rounds) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_last_em_work: null engine");
+  if (tile_sites) *tile_sites = e->em_counts[0];
+  if (table_rounds) *table_rounds = e->em_counts[1];
   return NGD_OK;
 }
 

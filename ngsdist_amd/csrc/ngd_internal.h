@@ -124,7 +124,7 @@ void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, co
 void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
                                const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
-                               double *slab);
+                               double *slab, unsigned long long *d_counters /* [2]: += (tile, site) visits, table rounds */);
 
 // rb (4, 8 or 16) replicates in one pass; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
 void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,

@@ -205,6 +205,12 @@ class Engine:
         _check(self._L.ngd_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def em_work(self):
+        """table-driven EM kernel: ((tile, site) visits, table rounds) of the last run"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.ngd_last_em_work(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def device_bytes(self):
         return int(self._L.ngd_device_bytes(self._h))
 

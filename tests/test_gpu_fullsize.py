@@ -94,15 +94,17 @@ def test_cfg3_streaming_kernel_agrees_on_every_pair(cfg3_mfma):
 
 
 def test_cfg4_em_forms_agree_on_every_pair():
-    """configs[3] shape (n_ind=1000, EM, JC69) on 20 000 sites: fast form vs the form whose iterates are
-    bit-identical to emOptim2.cpp's; plus the oracle on a few pairs."""
+    """configs[3] shape (n_ind=1000, EM, JC69) on 20 000 sites, every pair: the table-driven kernel and the per-pair
+    fast form vs the form whose iterates are bit-identical to emOptim2.cpp's; plus the oracle on a few pairs."""
     n_ind, n_sites = 1000, 20_000
     res = {}
-    for k in ("em_fast", "em_faithful"):
+    for k in ("em_table", "em_fast", "em_faithful"):
         with N().Engine(n_ind, n_sites, indep_geno=False, kernel=k) as e:
             res[k] = e.synth_fill(3).run()
-    assert np.array_equal(res["em_fast"][1], res["em_faithful"][1])
-    assert rel(res["em_fast"][0], res["em_faithful"][0]) < RTOL
+    for k in ("em_table", "em_fast"):
+        assert np.array_equal(res[k][1], res["em_faithful"][1])
+        assert rel(res[k][0], res["em_faithful"][0]) < RTOL
+    assert rel(res["em_table"][0], res["em_fast"][0]) < 1e-12
     idx = [0, 15, 16, 999]
     sub = np.concatenate([O.synth_indmajor(3, n_ind, n_sites, i0=i, n_sub=1) for i in idx])
     so, co = O.all_pairs(sub, indep_geno=False, n_threads=8)
@@ -175,3 +177,54 @@ def test_many_individuals_against_the_oracle():
     with N().Engine(n_ind, n_sites, kernel="mfma", pairwise_del=True) as e:
         s, c = e.synth_fill(9, 0.1).run()
     assert np.array_equal(c, co) and rel(s, so) < RTOL
+
+
+@pytest.fixture(scope="module")
+def cfg4_em():
+    """configs[3]: n_ind=1000, n_sites=1e6, GL, EM path (no --indep_geno), JC69 -- at its stated size"""
+    e = N().Engine(1000, 1_000_000, indep_geno=False, kernel="em_table")
+    e.synth_fill(3)
+    yield e
+    e.close()
+
+
+def test_cfg4_full_size_oracle_on_a_few_pairs_over_all_sites(cfg4_em):
+    """the EM of all 1e6 sites of 6 pairs on the CPU (the oracle's em2 is bit-identical to the reference's own,
+    tests/test_oracle_golden.py) against the device's 4.995e11 pair-sites; then the JC69 tail"""
+    e = cfg4_em
+    s, c = e.run()
+    assert np.all(c == 1_000_000)
+    idx = [0, 63, 64, 999]  # both sides of a tile edge, first and last individual
+    sub = np.concatenate([O.synth_indmajor(3, 1000, 1_000_000, i0=i, n_sub=1) for i in idx])
+    so, co = O.all_pairs(sub, indep_geno=False, n_threads=16)
+    k = 0
+    for a in range(len(idx)):
+        for b in range(a + 1, len(idx)):
+            g = s[N().n_pairs(1000) - N().n_pairs(1000 - idx[a]) + (idx[b] - idx[a] - 1)]
+            assert abs(g - so[k]) / so[k] < RTOL
+            k += 1
+    assert k == 6
+    with np.errstate(all="ignore"):
+        d = N().finish(s, c, 0, 2)
+    assert np.isfinite(d).all() and d.min() > 0
+    tile_sites, rounds = e.em_work()
+    assert tile_sites == 136 * 1_000_000 and 1.0 <= rounds / tile_sites <= 4.0
+
+
+def test_cfg4_full_size_block_additivity(cfg4_em):
+    """size-independent properties at full size: the sum over sites is additive over blocks of sites and depends
+    only on block multiplicities (the per-block partial sums of the bootstrap path vs the plain pass)"""
+    e = cfg4_em
+    B, nb = 10_000, 100
+    full, _ = e.run()
+    ident = np.arange(nb, dtype=np.uint64)
+    s_id, c_id = e.run(ident, B)
+    assert np.all(c_id == 1_000_000) and rel(s_id, full) < 1e-12
+    perm = np.random.default_rng(0).permutation(ident)
+    s_perm, _ = e.run(perm, B)
+    assert np.array_equal(s_perm, s_id)
+    lo = np.repeat(np.arange(nb // 2, dtype=np.uint64), 2)
+    hi = np.repeat(np.arange(nb // 2, nb, dtype=np.uint64), 2)
+    s_lo, _ = e.run(lo, B)
+    s_hi, _ = e.run(hi, B)
+    assert rel(s_lo + s_hi, 2 * full) < 1e-12
