@@ -10,14 +10,14 @@ ngsDist.cpp:372-401), with ONE collective per job when N > 1.
 Inputs are synthetic (counter-based generator), generated ON the GPU
 before the timed region.
 
-N > 1 (--shard):
-  replicates (default for the single-matrix workloads; weak scaling): matrices are independent units
-      (ngsDist.cpp:217-289), so every GPU holds the data set and computes ONE matrix of the job -- rank 0 the
-      full-data matrix, rank r the r-th bootstrap replicate at the reference's default --boot_block_size 1,
-      drawn from its taus stream -- and one RCCL all-gather brings the N finished matrices together;
-  sites (default for cfg5; strong scaling): each GPU holds 1/N of the sites of all individuals, computes every
-      pair over its range, partial sums are added by one RCCL reduce;
-  pairs (strong scaling): pair tiles dealt over GPUs, input replicated, disjoint results.
+N > 1 (--shard): the SAME job at every N unless --shard replicates is asked for.
+  sites (default; strong scaling): each GPU holds 1/N of the sites of all individuals and computes every pair over
+      its range; one RCCL reduce-scatter adds the partial sums and leaves each rank 1/N of the cells, whose tail
+      (/cnt, evolutionary model: host libm) it runs on its own host cores; one RCCL all-gather of the finished cells;
+  pairs (strong scaling): pair tiles dealt over GPUs, input replicated, disjoint results; same two collectives;
+  replicates (weak scaling, single-matrix workloads only: the job GROWS with N): every GPU holds the data set and
+      computes ONE matrix -- rank 0 the full-data matrix, rank r the r-th bootstrap replicate at the reference's
+      default --boot_block_size 1, drawn from its taus stream -- and one RCCL all-gather of the finished matrices.
 
 Prints ONE JSON line on rank 0 (see the task contract): metric/value/unit,
 `roofline` for the dominant kernel from HIP-event timings taken inside this run,
@@ -66,9 +66,10 @@ def main():
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicates", "sites", "pairs"],
-                    help="N>1: one matrix (bootstrap replicate) per GPU, or split the site axis (each rank holds 1/N "
-                         "of the data, all pairs; sums are added), or deal pair tiles over ranks (input replicated; "
-                         "disjoint results); auto = replicates for single-matrix workloads, sites for cfg5")
+                    help="N>1: split the site axis (each rank holds 1/N of the data, all pairs; sums are added), or deal "
+                         "pair tiles over ranks (input replicated; disjoint results) -- both time the SAME job at every "
+                         "N; or one matrix (bootstrap replicate) per GPU (weak scaling: the job grows with N); "
+                         "auto = sites")
     args = ap.parse_args()
 
     import numpy as np
@@ -76,14 +77,14 @@ def main():
     import torch.distributed as dist
 
     import ngsdist_amd as N
-    from ngsdist_amd.dist import gather_matrices, merge_shards
+    from ngsdist_amd.dist import gather_cells, gather_matrices, scatter_sum, share_of
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py: --gpus %d needs a torch.distributed.run launch" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (N > 1 needs a torch.distributed.run launch with "
+                         "--nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the product path has no CPU fallback")
     if args.same_device:
@@ -108,13 +109,13 @@ def main():
 
     shard = args.shard
     if shard == "auto":
-        shard = "replicates" if W["n_boot"] == 0 else "sites"
+        shard = "sites"
     if world == 1:
         shard = "none"
     by_sites, by_reps = shard == "sites", shard == "replicates"
     if by_reps:
         if W["n_boot"]:
-            raise SystemExit("bench.py: --shard replicates is for the single-matrix workloads (cfg5: use sites)")
+            raise SystemExit("bench.py: --shard replicates is for the single-matrix workloads")
         # one matrix per GPU: the full-data matrix + (N-1) bootstrap replicates at the reference's default block size
         W["n_boot"], W["block"] = world - 1, 1
 
@@ -136,9 +137,6 @@ def main():
                        shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world)
         eng.synth_fill(W["seed"], 0.0)
 
-    d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
-    d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
-    h_sum = torch.empty(n_pairs, dtype=torch.float64).pin_memory()
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
     # bootstrap workloads: replicate r>0 draws its block map from the reference's taus stream
@@ -148,35 +146,55 @@ def main():
     mults = [None if m is None else np.bincount(m.astype(np.int64), minlength=n_eff // W["block"]).astype(np.uint32)
              for m in maps]
 
-    cnt_full = np.full(n_pairs, n_sites, dtype=np.uint64)
     acc_ms, red_ms, tot_ms, pair_sites = [], [], [], []
     last = {}
+    on_gpu = args.backend == "nccl"  # collectives on device tensors (RCCL) or, in the rehearsal, on host tensors (gloo)
+    pin = lambda *shape: torch.empty(*shape, dtype=torch.float64).pin_memory()
 
     # Bootstrap workloads: all replicates of the job go to the engine in ONE call (ngd_run_mult_batch: per-block
     # partial sums once, then every replicate is a weighted reduction of them).  When the blocks cover the
     # whole data set the full-data matrix is the all-ones row of the same batch, otherwise it is its own pass.
     batched = W["n_boot"] > 0 and not by_reps
     if by_reps:
+        d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
+        d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
+        h_sum = pin(n_pairs)
         d_dist = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
-        h_dist = torch.empty(n_pairs, dtype=torch.float64).pin_memory()
+        h_dist = pin(n_pairs)
         d_all = torch.zeros((n_mat, n_pairs), dtype=torch.float64, device=dev)
-        h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
+        h_all = pin(n_mat, n_pairs)
         cnt_mine = np.full(n_pairs, n_sites if rank == 0 else n_eff, dtype=np.uint64)
+    else:
+        # the job's cells, flat: [n_mat][n_pairs], padded to `world` equal shares
+        total = n_mat * n_pairs
+        chunk, c_lo, c_hi = share_of(total, rank, world)
+        d_flat = torch.zeros(world * chunk, dtype=torch.float64, device=dev)  # the engine's (partial) sums
+        d_all = d_flat[:total].view(n_mat, n_pairs)
+        d_call = torch.zeros((n_mat, n_pairs), dtype=torch.int64, device=dev)
+        # no --pairwise_del in these workloads: a cell's count is the number of sites its matrix visits
+        cnt_flat = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
+        cnt_flat[0, :] = n_sites
+        cnt_flat = cnt_flat.reshape(-1)
+        if world > 1:
+            d_mine = torch.empty(chunk, dtype=torch.float64, device=dev)
+            h_mine, h_dist_mine = pin(chunk), pin(chunk)
+            h_dist_mine.zero_()
+            d_dist_mine = torch.empty(chunk, dtype=torch.float64, device=dev)
+            d_dist_all = torch.empty(world * chunk, dtype=torch.float64, device=dev)
+            h_dist_all = pin(world * chunk)
+            h_flat = pin(world * chunk) if not on_gpu else None
+        else:
+            h_all = pin(n_mat, n_pairs)
+            dist_all = np.zeros((n_mat, n_pairs))
+            copy_stream = torch.cuda.Stream()
+            step_m = max(1, n_mat // 8)
+            chunks = [(a, min(n_mat, a + step_m)) for a in range(0, n_mat, step_m)]
+            chunk_ev = [torch.cuda.Event() for _ in chunks]
     if batched:
         n_blocks = n_eff // W["block"]
         fold0 = n_eff == n_sites
         rows = ([np.ones(n_blocks, dtype=np.uint32)] if fold0 else []) + mults[1:]
         mult_all = np.ascontiguousarray(np.stack(rows)[:, blk_lo:blk_hi] if by_sites else np.stack(rows))
-        d_all = torch.zeros((n_mat, n_pairs), dtype=torch.float64, device=dev)
-        d_call = torch.zeros((n_mat, n_pairs), dtype=torch.int64, device=dev)
-        h_all = torch.empty((n_mat, n_pairs), dtype=torch.float64).pin_memory()
-        cnt_all = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
-        cnt_all[0, :] = n_sites
-        dist_all = np.zeros((n_mat, n_pairs))
-        copy_stream = torch.cuda.Stream()
-        step_m = max(1, n_mat // 8)
-        chunks = [(a, min(n_mat, a + step_m)) for a in range(0, n_mat, step_m)]
-        chunk_ev = [torch.cuda.Event() for _ in chunks]
 
     def record_timing():
         t = eng.timing()
@@ -191,23 +209,21 @@ def main():
             eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr(), maps[rank], W["block"])
             if record:
                 record_timing()
-            if args.backend == "nccl":
-                h_sum.copy_(d_sum, non_blocking=True)
-                torch.cuda.synchronize()
-            else:
-                h_sum.copy_(d_sum)
+            h_sum.copy_(d_sum, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
             with np.errstate(all="ignore"):
                 N.finish(h_sum.numpy(), cnt_mine, 0, W["evol_model"], out=h_dist.numpy())
-            if args.backend == "nccl":
+            if on_gpu:
                 d_dist.copy_(h_dist, non_blocking=True)
                 gather_matrices(d_all, d_dist)
                 if rank == 0:
                     h_all.copy_(d_all, non_blocking=True)
-                    torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()  # every rank: the collective is over before the next step
             else:
                 gather_matrices(h_all, h_dist)
             last["dist"] = h_all[-1].numpy()
             return
+        # the job's (partial) sums, every matrix: one engine call per plan
         if batched:
             first = 0 if fold0 else 1
             if not fold0:
@@ -216,49 +232,47 @@ def main():
                     record_timing()
             eng.run_batch(mult=mult_all, block_size=W["block"], d_sum_ptr=d_all[first].data_ptr(),
                           d_cnt_ptr=d_call[first].data_ptr())
-            if record:
-                record_timing()
-            if args.backend == "nccl":
-                merge_shards(d_all, None, dst=0)  # ONE RCCL collective for the whole job
-                if rank == 0:
-                    # results leave the device in chunks of matrices; the host tail (ngd_finish) of one chunk
-                    # runs while the next is in flight
-                    copy_stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(copy_stream):
-                        for c, (a, b) in enumerate(chunks):
-                            h_all[a:b].copy_(d_all[a:b], non_blocking=True)
-                            chunk_ev[c].record(copy_stream)
-                    with np.errstate(all="ignore"):
-                        for c, (a, b) in enumerate(chunks):
-                            chunk_ev[c].synchronize()
-                            N.finish(h_all[a:b].numpy().reshape(-1), cnt_all[a:b].reshape(-1), 0, W["evol_model"],
-                                     out=dist_all[a:b].reshape(-1))
-                    last["dist"] = dist_all[-1]
-            else:
-                h_all.copy_(d_all)
-                merge_shards(h_all, None, dst=0)
-                if rank == 0:
-                    with np.errstate(all="ignore"):
-                        N.finish(h_all.numpy().reshape(-1), cnt_all.reshape(-1), 0, W["evol_model"],
-                                 out=dist_all.reshape(-1))
-                    last["dist"] = dist_all[-1]
-            return
-        eng.run_device(d_sum.data_ptr(), d_cnt.data_ptr())
+        else:
+            eng.run_device(d_all[0].data_ptr(), d_call[0].data_ptr())
         if record:
             record_timing()
-        # no --pairwise_del in these workloads: every pair's count is the number of sites visited,
-        # so only the sums travel (one collective); rank 0 fills the counts in.
-        if args.backend == "nccl":
-            merge_shards(d_sum, None, dst=0)  # ONE RCCL collective; shards are disjoint / partial sums add
-            if rank == 0:
-                h_sum.copy_(d_sum, non_blocking=True)
-                torch.cuda.synchronize()
-        else:  # rehearsal: merge on the host over gloo
-            h_sum.copy_(d_sum)
-            merge_shards(h_sum, None, dst=0)
-        if rank == 0:
+        if world == 1:
+            # results leave the device in chunks of matrices; the host tail (ngd_finish) of one chunk runs while
+            # the next is in flight
+            copy_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(copy_stream):
+                for c, (a, b) in enumerate(chunks):
+                    h_all[a:b].copy_(d_all[a:b], non_blocking=True)
+                    chunk_ev[c].record(copy_stream)
             with np.errstate(all="ignore"):
-                last["dist"] = N.finish(h_sum.numpy(), cnt_full, 0, W["evol_model"])
+                for c, (a, b) in enumerate(chunks):
+                    chunk_ev[c].synchronize()
+                    N.finish(h_all[a:b].numpy().reshape(-1), cnt_flat[a * n_pairs:b * n_pairs], 0, W["evol_model"],
+                             out=dist_all[a:b].reshape(-1))
+            last["dist"] = dist_all[-1]
+            return
+        # N > 1: reduce-scatter (partial sums add / disjoint shards meet) -> every rank finishes its share of the
+        # cells on its own host cores -> all-gather of the finished cells
+        if on_gpu:
+            scatter_sum(d_flat, d_mine)
+            h_mine.copy_(d_mine, non_blocking=True)
+            # also: the collective has read d_flat before the engine (its own stream) may write it again
+            torch.cuda.current_stream().synchronize()
+        else:
+            h_flat.copy_(d_flat)
+            scatter_sum(h_flat, h_mine)
+        with np.errstate(all="ignore"):
+            N.finish(h_mine.numpy()[:c_hi - c_lo], cnt_flat[c_lo:c_hi], 0, W["evol_model"],
+                     out=h_dist_mine.numpy()[:c_hi - c_lo])
+        if on_gpu:
+            d_dist_mine.copy_(h_dist_mine, non_blocking=True)
+            gather_cells(d_dist_all, d_dist_mine)
+            if rank == 0:
+                h_dist_all.copy_(d_dist_all, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            gather_cells(h_dist_all, h_dist_mine)
+        last["dist"] = h_dist_all.numpy()[:total].reshape(n_mat, n_pairs)[-1]
 
     def fence():
         if world > 1:
@@ -270,16 +284,12 @@ def main():
         dist.all_reduce(t, op=op)
         return float(t.item())
 
-    if world > 1:  # communicator and buffers come up outside the timed region whatever --warmup is
+    if world > 1:  # communicators and buffers come up outside the timed region whatever --warmup is
         if by_reps:
-            if args.backend == "nccl":
-                gather_matrices(d_all, d_dist)
-            else:
-                gather_matrices(h_all, h_dist)
-        elif args.backend == "nccl":
-            merge_shards(d_all if batched else d_sum, None, dst=0)
+            gather_matrices(d_all if on_gpu else h_all, d_dist if on_gpu else h_dist)
         else:
-            merge_shards(h_all if batched else h_sum, None, dst=0)
+            scatter_sum(d_flat if on_gpu else h_flat, d_mine if on_gpu else h_mine)
+            gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -324,7 +334,7 @@ def main():
                 g = last["dist"][N.n_pairs(n_ind) - N.n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
                 worst = max(worst, abs(g - do[k]) / abs(do[k]))
                 k += 1
-        spot = {"pairs": k, "sites": int(n_eff if src is not None else n_sites), "max_rel_err_vs_oracle": worst}
+        spot = {"pairs": k, "sites": int(n_eff if src is not None else n_sites), "max_rel_err_vs_oracle": float(worst)}
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 figure
             cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
             rate_guess = (1.7e8 if W["indep"] else 2.8e6) * cores  # pair-sites/s per thread, measured
@@ -355,8 +365,9 @@ def main():
                                                       "pair (0,1); excludes gen_dist's loop around it" % m}
                 except Exception as exc:
                     cpu["reference_em2"] = {"error": repr(exc)}
-    except Exception as exc:  # the oracle is a checker; never let it take the bench line down
+    except Exception as exc:  # reported in the line, which is then marked invalid (exit code 1)
         cpu = {"error": repr(exc)}
+    valid = bool(spot is not None and spot["max_rel_err_vs_oracle"] <= 1e-9)
 
     t_acc = acc_mean_ms * 1e-3
     if W["indep"]:
@@ -417,7 +428,7 @@ def main():
     out = {
         "metric": "pair-distances/sec", "value": value, "unit": "pair-distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak" if by_reps or (world == 1 and not W["n_boot"] and args.shard in ("auto", "replicates")) else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if by_reps or (world == 1 and args.shard == "replicates") else "strong", "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s: n_ind=%d n_sites=%d %s evol_model=%d n_boot_rep=%d boot_block_size=%d"
@@ -425,19 +436,23 @@ def main():
                                   W["evol_model"], W["n_boot"], W["block"]),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
-                   "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs), sums added by "
-                                "one RCCL reduce" % (world, world)) if by_sites else
+                   "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "
+                                "reduce-scatter adds the sums, every rank finishes its 1/%d of the cells on its host, one "
+                                "RCCL all-gather" % (world, world, world)) if by_sites else
                                ("one matrix per GPU (full data + %d bootstrap replicates, block size 1), data set "
                                 "resident on every GPU, one RCCL all-gather of the finished matrices" % (world - 1))
                                if by_reps else
                                ("pair tiles dealt over %d rank(s), input replicated" % world)},
-        "roofline": roof, "cpu_baseline": cpu, "spot_check": spot,
+        "roofline": roof, "cpu_baseline": cpu, "spot_check": spot, "valid": valid,
         "device_bytes": eng.device_bytes(),
         "ms_reduce": float(np.mean(red_ms)), "ms_engine_total": float(np.mean(tot_ms)),
     }
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if not valid:
+        sys.stderr.write("bench.py: the spot check against the CPU oracle failed or did not run: %r\n" % (spot or cpu,))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

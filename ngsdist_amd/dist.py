@@ -1,9 +1,14 @@
-"""Multi-GPU plumbing: one process per GPU and ONE collective per job.
-Replicate sharding (one finished matrix per rank): gather_matrices().
-Pair-tile / site sharding: merge_shards() brings the shards to rank 0.  Because every pair is owned by exactly one rank and the others hold
-exact zeros, a SUM reduce is a gather: x + 0 is exact in IEEE arithmetic (sums
-are >= +0, so no -0 ambiguity).  Backend "nccl" (= RCCL over xGMI) on GPUs,
-"gloo" in the CPU tests.
+"""Multi-GPU plumbing: one process per GPU, collectives only where a job has an exchange step.
+
+A job = n_mat matrices of n_pairs cells (the replicate loop, ngsDist.cpp:217-289).  Three ways to split it:
+  * site or pair-tile sharding (strong scaling: the same job at every N): every rank holds partial sums of every
+    cell (site ranges: to be added; pair tiles: zeros outside its shard, and x + 0 is exact).  scatter_sum() adds
+    them AND leaves each rank with 1/N of the cells (one RCCL reduce-scatter), so that the tail of gen_dist()
+    (ngsDist.cpp:372-401: /cnt, evolutionary model, on the HOST's libm for byte-identical output) runs on every
+    rank's host cores for its own share; gather_cells() then puts the finished cells together (one all-gather).
+  * replicate sharding (weak scaling: one matrix per rank): gather_matrices(), one all-gather of finished matrices.
+merge_shards() is the plain reduce to one rank (what a host that wants raw sums uses).
+Backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 """
 import numpy as np
 
@@ -35,6 +40,33 @@ def merge_shards(sum_t, cnt_t, dst=0):
         dist.reduce(cnt_t, dst=dst, op=dist.ReduceOp.SUM)
 
 
+def share_of(total, rank, world):
+    """(chunk, lo, hi): cells [lo, hi) of `total` belong to `rank`; every rank's buffer holds `chunk` cells
+    (the last ranks' tails are padding: reduce-scatter and all-gather want equal shares)"""
+    chunk = -(-total // world)
+    lo = min(total, rank * chunk)
+    return chunk, lo, min(total, lo + chunk)
+
+
+def scatter_sum(flat_t, mine_t):
+    """flat_t: [world * chunk] partial sums of every cell (padding zeroed); after the call mine_t ([chunk]) holds
+    the SUM over ranks of this rank's share.  One reduce-scatter."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        mine_t.copy_(flat_t[:mine_t.numel()])
+        return
+    dist.reduce_scatter_tensor(mine_t, flat_t, op=dist.ReduceOp.SUM)
+
+
+def gather_cells(all_t, mine_t):
+    """all_t: [world * chunk]; after the call every rank holds every rank's share, in rank order.  One all-gather."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        all_t[:mine_t.numel()].copy_(mine_t)
+        return
+    dist.all_gather_into_tensor(all_t, mine_t)
+
+
 def gather_matrices(all_t, mine_t):
     """Replicate sharding: rank r holds one finished matrix (mine_t, [n_pairs]); after the call every rank's
     all_t ([world][n_pairs], same device and dtype) holds all of them, row r = rank r's.  One all-gather."""
@@ -42,7 +74,7 @@ def gather_matrices(all_t, mine_t):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         all_t[0].copy_(mine_t)
         return
-    if dist.get_backend() == "nccl" and all_t.is_contiguous():
-        dist.all_gather_into_tensor(all_t, mine_t)  # RCCL's native all-gather into the [world][n_pairs] tensor
+    if all_t.is_contiguous():
+        dist.all_gather_into_tensor(all_t.view(-1), mine_t)  # the native all-gather, rows of all_t in rank order
     else:
         dist.all_gather(list(all_t.unbind(0)), mine_t)

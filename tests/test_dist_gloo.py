@@ -154,3 +154,80 @@ def test_two_rank_replicate_sharding_gathers_whole_matrices():
         pr.join(300)
         assert pr.exitcode == 0
     assert q.get(timeout=10)
+
+
+def _job_worker(rank, world, port, n_ind, n_sites, n_boot, block, q):
+    """bench.py's strong-scaling flow for a multi-matrix job (cfg 5's shape in small): site ranges -> per-rank partial
+    sums of every matrix -> scatter_sum (reduce-scatter) -> each rank finishes its share of the cells on its host ->
+    gather_cells (all-gather).  Called genotypes, so the partial sums add up exactly and every cell must equal the
+    single-process result bit for bit."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import ngsdist_amd as N
+    from ngsdist_amd.dist import gather_cells, scatter_sum, share_of
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    n_pairs, n_mat = N.n_pairs(n_ind), n_boot + 1
+    n_eff = n_sites - n_sites % block
+    t = O.Taus(12345)
+    maps = [None] + [t.block_map(n_eff // block) for _ in range(n_boot)]
+    # whole blocks per rank
+    n_blocks = n_eff // block
+    b_lo, b_hi = n_blocks * rank // world, n_blocks * (rank + 1) // world
+    s_lo, s_hi = b_lo * block, (b_hi * block if rank + 1 < world else n_sites)
+    total = n_mat * n_pairs
+    chunk, c_lo, c_hi = share_of(total, rank, world)
+    flat = torch.zeros(world * chunk, dtype=torch.float64)
+    part = flat[:total].view(n_mat, n_pairs)
+    for m, bm in enumerate(maps):  # stand-in for the device kernels: this rank's sites of every matrix
+        if bm is None:
+            src = np.arange(s_lo, s_hi, dtype=np.uint64)
+        else:  # the draws that land in this rank's blocks, in this rank's positions -- multiplicities are what matter
+            mult = np.bincount(bm.astype(np.int64), minlength=n_blocks)[b_lo:b_hi]
+            src = np.concatenate([np.tile(np.arange(b * block, (b + 1) * block, dtype=np.uint64), k)
+                                  for b, k in zip(range(b_lo, b_hi), mult)] or [np.zeros(0, dtype=np.uint64)])
+        if src.size:
+            part[m] = torch.from_numpy(O.all_pairs(p, site_src=src, n_sites=src.size)[0])
+    mine = torch.empty(chunk, dtype=torch.float64)
+    scatter_sum(flat, mine)
+    cnt = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
+    cnt[0] = n_sites
+    dist_mine = torch.zeros(chunk, dtype=torch.float64)
+    with np.errstate(all="ignore"):
+        N.finish(mine.numpy()[:c_hi - c_lo], cnt.reshape(-1)[c_lo:c_hi], 0, 1, out=dist_mine.numpy()[:c_hi - c_lo])
+    every = torch.empty(world * chunk, dtype=torch.float64)
+    gather_cells(every, dist_mine)
+    got = every.numpy()[:total].reshape(n_mat, n_pairs)
+    ok = True
+    for m, bm in enumerate(maps):  # single-process result
+        src = None if bm is None else O.boot_site_src(bm, block)
+        s, c = O.all_pairs(p, site_src=src, n_sites=n_sites if bm is None else n_eff)
+        with np.errstate(all="ignore"):
+            ok = ok and np.array_equal(got[m], O.finish(s, c, 0, 1), equal_nan=True)
+    q.put((rank, bool(ok), c_hi - c_lo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_job_reduce_scatter_finish_all_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, 13, 403, 4, 10, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert all(ok for _, ok, _ in res)          # every rank ends up with every finished cell
+    assert sum(n for _, _, n in res) == 5 * 78  # the shares partition the job's cells
