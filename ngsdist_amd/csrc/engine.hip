@@ -480,8 +480,7 @@ static int stage_init(ngd_engine *e) {
     if (rc) return rc;
     HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
   }
-  int rc = dev_alloc(e, &e->d_nan, 1, true);
-  return rc;
+  return e->d_nan ? NGD_OK : dev_alloc(e, &e->d_nan, 1, true);
 }
 
 int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites) {
@@ -543,8 +542,14 @@ int ngd_commit(ngd_engine *e) {
     for (int b = 0; b < 2; b++) {  // the pipeline is over: give its buffers back
       if (e->pin[b]) { HIPCHK(hipHostFree(e->pin[b])); e->pin[b] = nullptr; }
       if (e->draw[b]) { HIPCHK(hipFree(e->draw[b])); e->draw[b] = nullptr; e->dev_bytes -= e->pin_sites * e->g.n_ind * 24; }
+      if (e->pin_free[b]) { HIPCHK(hipEventDestroy(e->pin_free[b])); e->pin_free[b] = nullptr; }
     }
-    if (flag) return fail(NGD_E_NAN, "NaN found! Is the file format correct?");
+    e->pin_cur = 0;
+    e->pin_lent = -1;
+    if (flag) {  // reported once: a caller that uploads again starts from a clean flag and a fresh pipeline
+      HIPCHK(hipMemset(e->d_nan, 0, sizeof(int)));
+      return fail(NGD_E_NAN, "NaN found! Is the file format correct?");
+    }
   }
   if (e->staging) {  // upload is over: give the staging buffer back
     HIPCHK(hipFree(e->staging));

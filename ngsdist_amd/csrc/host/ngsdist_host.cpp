@@ -19,8 +19,11 @@
 //    stream is handed to ngd_run();
 //  * a file name without a '.' is treated as binary instead of dereferencing
 //    NULL (ngsDist.cpp:82);
-//  * extra options: --n_gpus N (pair tiles dealt over N devices of this node),
-//    --device D (first device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful,
+//  * extra options: --n_gpus N (the SITE axis split over N devices of this node: every device reads and holds its own
+//    range of sites and computes all pairs over it; the per-range sums are added -- byte-identical output for called
+//    genotypes, <= 1e-12 relative otherwise), --device D (first device), --same_device (every range on --device: a
+//    rehearsal on one GPU), --max_device_bytes B (device budget; a data set above it goes through in several ranges
+//    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful,
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -67,6 +70,8 @@ struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
   unsigned n_threads = 1, verbose = 1, seed = 0;
   // engine placement (not in the reference)
   int n_gpus = 1, device = 0, kernel = NGD_KERNEL_AUTO;
+  bool same_device = false;      // --same_device
+  uint64_t max_device_bytes = 0; // --max_device_bytes (0 = 85 % of the device's free memory)
   int prep = 0;  // 0 auto (device unless genotypes are called), 1 host, 2 device
 };
 
@@ -112,6 +117,8 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
                                  {"verbose", required_argument, nullptr, 'V'},
                                  {"seed", required_argument, nullptr, 'r'},
                                  {"n_gpus", required_argument, nullptr, 1001},
+                                 {"same_device", no_argument, nullptr, 1005},
+                                 {"max_device_bytes", required_argument, nullptr, 1006},
                                  {"device", required_argument, nullptr, 1002},
                                  {"kernel", required_argument, nullptr, 1003},
                                  {"prep", required_argument, nullptr, 1004},
@@ -144,6 +151,8 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
       case 'V': p.verbose = (unsigned)atoi(optarg); break;
       case 'r': p.seed = (unsigned)atoi(optarg); break;
       case 1001: p.n_gpus = atoi(optarg); break;
+      case 1005: p.same_device = true; break;
+      case 1006: p.max_device_bytes = strtoull(optarg, nullptr, 10); break;
       case 1002: p.device = atoi(optarg); break;
       case 1003:
         if (!strcmp(optarg, "auto")) p.kernel = NGD_KERNEL_AUTO;
@@ -362,24 +371,28 @@ static void parallel_for(unsigned n_threads, uint64_t n, uint64_t min_n, F fn) {
 }
 
 // ---------------------------------------------------------------------------
-struct Engines {
-  std::vector<ngd_engine *> e;
+// one engine, destroyed with its scope
+struct Engine {
+  ngd_engine *h = nullptr;
+  Engine() = default;
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
   void upload_sites(const double *p, uint64_t s0, uint64_t n) {
-    for (auto *h : e) { int rc = ngd_upload_sites(h, p, s0, n); if (rc) die_engine("upload", rc); }
+    int rc = ngd_upload_sites(h, p, s0, n);
+    if (rc) die_engine("upload", rc);
   }
   void commit() {
-    for (auto *h : e) {
-      int rc = ngd_commit(h);
-      if (rc == NGD_E_NAN) die("read_geno", "NaN found! Is the file format correct?");
-      if (rc) die_engine("commit", rc);
-    }
+    int rc = ngd_commit(h);
+    if (rc == NGD_E_NAN) die("read_geno", "NaN found! Is the file format correct?");
+    if (rc) die_engine("commit", rc);
   }
-  ~Engines() { for (auto *h : e) ngd_destroy(h); }
+  ~Engine() { if (h) ngd_destroy(h); }
 };
 
 // read_geno(), read_data.cpp:13-116, fused with the preparation and the upload.  The input is consumed front to
-// back in one or more parts (a data set larger than the device goes through it a range of sites at a time):
-// load() puts the next n_part sites into the engines as their sites 0 .. n_part-1 and commits them.
+// back in one or more parts (ranges of sites: one per device, or several when the data set is larger than the
+// devices): load() puts the next n_part sites into an engine as its sites 0 .. n_part-1 and commits them.  A plain
+// binary file can also be entered at any site (first_site), so that every device's thread reads its own ranges.
 struct Loader {
   const Pars &p;
   gzFile fh = nullptr;
@@ -387,12 +400,13 @@ struct Loader {
   uint64_t raw_off = 0, raw_size = 0;
   uint64_t done = 0;  // sites of the whole input consumed by earlier parts
   bool eof = false;
-  explicit Loader(const Pars &pars);
-  void load(Engines &eng, uint64_t n_part, bool last_part);
-  void finish();
+  explicit Loader(const Pars &pars, uint64_t first_site = 0);
+  bool seekable() const { return raw_fd >= 0; }
+  void load(Engine &eng, uint64_t n_part, bool last_part);
+  void finish(bool check_eof = true);
 };
 
-Loader::Loader(const Pars &pars) : p(pars) {
+Loader::Loader(const Pars &pars, uint64_t first_site) : p(pars) {
   fh = open_gz(p.in_geno, p.in_bin ? "rb" : "r");
   if (!fh) die("read_geno", "cannot open GENO file!");
   // A binary GL file that is a plain regular file (the usual case; gzread would only copy it through) is read
@@ -406,13 +420,15 @@ Loader::Loader(const Pars &pars) : p(pars) {
         !(magic[0] == 0x1f && magic[1] == 0x8b)) {
       raw_fd = fd;
       raw_size = (uint64_t)st.st_size;
+      raw_off = first_site * p.n_ind * 24;
+      done = first_site;
     } else if (fd >= 0) {
       close(fd);
     }
   }
 }
 
-void Loader::load(Engines &eng, uint64_t n_part, bool last_part) {
+void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
   const uint64_t n_ind = p.n_ind, n_sites = n_part;
   const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_sites, (64ull << 20) / (n_ind * 24)));
   std::vector<double> buf(chunk * n_ind * 3);
@@ -457,19 +473,15 @@ void Loader::load(Engines &eng, uint64_t n_part, bool last_part) {
     for (uint64_t s0 = 0; s0 < n_sites;) {
       double *pin; uint64_t cap;
       auto t0 = now();
-      int rc = ngd_stage_acquire(eng.e[0], &pin, &cap);
+      int rc = ngd_stage_acquire(eng.h, &pin, &cap);
       if (rc) die_engine("ngd_stage_acquire", rc);
       const uint64_t n = std::min(cap, n_sites - s0);
       auto t1 = now();
       read_exact(pin, n * n_ind * 24);
       auto t2 = now();
       t_acq += secs(t0, t1); t_read += secs(t1, t2);
-      for (size_t r = 1; r < eng.e.size(); r++) {
-        rc = ngd_upload_raw_sites(eng.e[r], pin, s0, n, &pr);
-        if (rc) die_engine("ngd_upload_raw_sites", rc);
-      }
       auto t3 = now();
-      rc = ngd_stage_submit(eng.e[0], s0, n, &pr);
+      rc = ngd_stage_submit(eng.h, s0, n, &pr);
       if (rc) die_engine("ngd_stage_submit", rc);
       t_sub += secs(t3, now());
       s0 += n;
@@ -577,9 +589,9 @@ void Loader::load(Engines &eng, uint64_t n_part, bool last_part) {
   eng.commit();
 }
 
-void Loader::finish() {
+void Loader::finish(bool check_eof) {
   if (raw_fd >= 0) {
-    if (raw_off != raw_size) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
+    if (check_eof && raw_off != raw_size) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
     close(raw_fd);
   } else {
     char one;
@@ -587,12 +599,6 @@ void Loader::finish() {
     if (!gzeof(fh)) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
   }
   gzclose(fh);
-}
-
-static void load_and_upload(const Pars &p, Engines &eng) {
-  Loader L(p);
-  L.load(eng, p.n_sites, true);
-  L.finish();
 }
 
 int main(int argc, char **argv) {
@@ -666,36 +672,30 @@ int main(int argc, char **argv) {
     if (pos.size() != p.n_sites || n_fields < 2) die(__FUNCTION__, "invalid POS file!");
   }
 
-  // engines: pair tiles dealt over --n_gpus devices, input replicated
+  // devices: --n_gpus of them, the site axis split over them
   int n_dev = ngd_device_count();
   if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
-  // NGD_HOST_SAME_DEVICE=1: every shard on --device (rehearses the multi-GPU merge on a 1-GPU box)
-  const bool same_device = getenv("NGD_HOST_SAME_DEVICE") && atoi(getenv("NGD_HOST_SAME_DEVICE")) != 0;
-  if (p.device + (same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
-  auto make_engines = [&](Engines &eng, uint64_t n_sites_part, int n_gpus) {
-    for (int r = 0; r < n_gpus; r++) {
-      ngd_config cfg;
-      memset(&cfg, 0, sizeof(cfg));
-      cfg.n_ind = p.n_ind;
-      cfg.n_sites = n_sites_part;
-      memcpy(cfg.score, p.score, sizeof(cfg.score));
-      cfg.pairwise_del = p.pairwise_del;
-      cfg.indep_geno = p.indep_geno;
-      cfg.device = same_device ? p.device : p.device + r;
-      cfg.kernel = p.kernel;
-      cfg.shard_rank = (uint32_t)r;
-      cfg.shard_world = (uint32_t)n_gpus;
-      ngd_engine *h = nullptr;
-      int rc = ngd_create(&cfg, &h);
-      if (rc) die_engine("ngd_create", rc);
-      eng.e.push_back(h);
-    }
+  if (p.device + (p.same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
+  auto make_engine = [&](Engine &eng, uint64_t n_sites_part, int dev_index) {
+    ngd_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.n_ind = p.n_ind;
+    cfg.n_sites = n_sites_part;
+    memcpy(cfg.score, p.score, sizeof(cfg.score));
+    cfg.pairwise_del = p.pairwise_del;
+    cfg.indep_geno = p.indep_geno;
+    cfg.device = p.same_device ? p.device : p.device + dev_index;
+    cfg.kernel = p.kernel;
+    int rc = ngd_create(&cfg, &eng.h);
+    if (rc) die_engine("ngd_create", rc);
   };
 
-  // Does the data set fit the device?  Resident bytes per site: both operand images (one on the EM path, the
-  // individual-major copy for the streaming kernel), masks and bootstrap weights; plus slabs and results.  If not,
-  // the input goes through ONE engine a range of sites at a time and the per-range (sum, cnt) are added (the site
-  // axis sharded in time; include/ngsdist_amd.h "Site sharding").
+  // Does the data set fit ONE device?  Resident bytes per site: both operand images (one on the EM path, the
+  // individual-major copy for the streaming kernel), masks and bootstrap weights; plus slabs and results.  If it
+  // does and one device is asked for, one engine runs the whole job (ngd_run_job).  Otherwise gen_dist()'s sums are
+  // split along the SITE axis (include/ngsdist_amd.h "Site sharding"): ranges of sites, each read, held and computed
+  // by one device -- side by side on --n_gpus devices, one after the other where the devices are too small -- and
+  // the per-range (sum, cnt) are added.
   const uint64_t n_pad = (p.n_ind + 127) / 128 * 128;
   const bool mfma_path = p.indep_geno && p.kernel != NGD_KERNEL_STREAM;
   const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path ? 48 : 24) * n_pad) +
@@ -704,10 +704,9 @@ int main(int argc, char **argv) {
   const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);
   uint64_t dev_free = 0, dev_total = 0;
   if (ngd_device_memory(p.device, &dev_free, &dev_total)) die_engine("ngd_device_memory", -1);
-  uint64_t budget = dev_free / 100 * 85;
-  if (getenv("NGD_HOST_MAX_BYTES")) budget = strtoull(getenv("NGD_HOST_MAX_BYTES"), nullptr, 10);
-  const bool in_parts = fixed + per_site * p.n_sites > budget;
-  if (in_parts && p.n_gpus > 1) die(__FUNCTION__, "the data set does not fit one device; --n_gpus replicates it (use one GPU)");
+  if (p.same_device) dev_free /= (uint64_t)p.n_gpus;  // the rehearsal's ranges share one device
+  const uint64_t budget = p.max_device_bytes ? p.max_device_bytes : dev_free / 100 * 85;
+  const bool in_parts = p.n_gpus > 1 || fixed + per_site * p.n_sites > budget;
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];
@@ -766,18 +765,24 @@ int main(int argc, char **argv) {
   const uint64_t kBatch = 32;
   fflush(stdout);
   if (in_parts) {
-    // ---- the data set is larger than the device: ranges of sites through one engine, sums added ----
+    // ---- the site axis in ranges: side by side on the devices, one after the other where they are too small ----
     const uint64_t B = p.boot_block_size;
     const uint64_t n_eff = p.n_boot_rep ? p.n_sites - p.n_sites % B : 0, n_blocks = p.n_boot_rep ? n_eff / B : 0;
     uint64_t unit = 16;  // ranges are whole 16-site groups and whole bootstrap blocks
     if (p.n_boot_rep) { uint64_t a = 16, b = B; while (b) { uint64_t t = a % b; a = b; b = t; } unit = 16 / a * B; }
     if (budget <= fixed || (budget - fixed) / per_site < unit)
       die(__FUNCTION__, "not even one range of sites (16 sites / one bootstrap block) fits the device");
-    const uint64_t part = (budget - fixed) / per_site / unit * unit;
+    const uint64_t cap = (budget - fixed) / per_site / unit * unit;  // sites one device holds
+    const uint64_t n_units = (p.n_sites + unit - 1) / unit;
+    const uint64_t G = (uint64_t)p.n_gpus;
+    const uint64_t part = std::min(cap, (n_units + G - 1) / G * unit);
     const uint64_t n_parts = (p.n_sites + part - 1) / part;
-    if (p.verbose >= 1)
-      fprintf(stderr, "==> Data set larger than the device budget (%.1f GB): %lu ranges of up to %lu sites\n", budget / 1e9,
-              n_parts, part);
+    if (p.verbose >= 1) {
+      if (part < (n_units + G - 1) / G * unit)
+        fprintf(stderr, "==> Data set larger than the device budget (%.1f GB): %lu ranges of up to %lu sites\n", budget / 1e9,
+                n_parts, part);
+      if (G > 1) fprintf(stderr, "==> Site axis split over %lu devices: %lu ranges of up to %lu sites\n", G, n_parts, part);
+    }
     // every replicate's block multiplicities, drawn in the reference's order before any data is read
     std::vector<uint32_t> mult((uint64_t)p.n_boot_rep * n_blocks, 0);
     std::vector<uint64_t> maps_kept;
@@ -790,56 +795,107 @@ int main(int argc, char **argv) {
       }
     }
     const uint64_t n_mat = p.n_boot_rep + 1;
-    std::vector<double> tot_sum(n_mat * n_comb, 0.0), ps;
-    std::vector<uint64_t> tot_cnt(n_mat * n_comb, 0), pc;
-    std::vector<uint32_t> mpart;
-    if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
-    Loader L(p);
-    double t_load = 0;
-    for (uint64_t c0 = 0; c0 < p.n_sites; c0 += part) {
-      const uint64_t c1 = std::min(p.n_sites, c0 + part);
-      Engines eng;
-      make_engines(eng, c1 - c0, 1);
-      const auto t_l0 = std::chrono::steady_clock::now();
-      L.load(eng, c1 - c0, c1 == p.n_sites);
-      t_load += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_l0).count();
+    // per device: the sums of its ranges, added in ascending range order; devices are added in device order at the
+    // end -- a fixed order of additions for given --n_gpus and budget
+    std::vector<std::vector<double>> dev_sum(G);
+    std::vector<std::vector<uint64_t>> dev_cnt(G);
+    std::vector<double> dev_secs(G, 0.0);
+    // all matrices of one range: the full data set (ngd_run), then the replicates from their block multiplicities
+    auto compute_range = [&](Engine &eng, uint64_t c0, uint64_t c1, uint64_t d) {
       const auto t_c0 = std::chrono::steady_clock::now();
-      ps.resize(kBatch * n_comb); pc.resize(kBatch * n_comb);
-      int rc = ngd_run(eng.e[0], nullptr, 0, 0, ps.data(), pc.data());
+      std::vector<double> &ts = dev_sum[d];
+      std::vector<uint64_t> &tc = dev_cnt[d];
+      if (ts.empty()) { ts.assign(n_mat * n_comb, 0.0); tc.assign(n_mat * n_comb, 0); }
+      std::vector<double> ps(std::min<uint64_t>(kBatch, n_mat) * n_comb);
+      std::vector<uint64_t> pc(ps.size());
+      int rc = ngd_run(eng.h, nullptr, 0, 0, ps.data(), pc.data());
       if (rc) die_engine("ngd_run", rc);
-      for (uint64_t k = 0; k < n_comb; k++) { tot_sum[k] += ps[k]; tot_cnt[k] += pc[k]; }
+      for (uint64_t k = 0; k < n_comb; k++) { ts[k] += ps[k]; tc[k] += pc[k]; }
       const uint64_t blk_lo = std::min(c0, n_eff) / (B ? B : 1), blk_hi = std::min(c1, n_eff) / (B ? B : 1);
       const uint64_t nb = blk_hi - blk_lo;  // this range's blocks (none in a range of tail sites only)
+      std::vector<uint32_t> mpart;
       for (uint64_t r0 = 0; nb && r0 < p.n_boot_rep; r0 += kBatch) {
         const uint64_t nr = std::min<uint64_t>(kBatch, p.n_boot_rep - r0);
         mpart.resize(nr * nb);
         for (uint64_t r = 0; r < nr; r++)
           memcpy(&mpart[r * nb], &mult[(r0 + r) * n_blocks + blk_lo], nb * sizeof(uint32_t));
-        rc = ngd_run_mult_batch(eng.e[0], mpart.data(), (uint32_t)nr, nb, B, ps.data(), pc.data());
+        rc = ngd_run_mult_batch(eng.h, mpart.data(), (uint32_t)nr, nb, B, ps.data(), pc.data());
         if (rc) die_engine("ngd_run_mult_batch", rc);
         for (uint64_t k = 0; k < nr * n_comb; k++) {
-          tot_sum[(1 + r0) * n_comb + k] += ps[k];
-          tot_cnt[(1 + r0) * n_comb + k] += pc[k];
+          ts[(1 + r0) * n_comb + k] += ps[k];
+          tc[(1 + r0) * n_comb + k] += pc[k];
         }
       }
-      t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
+      dev_secs[d] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
+    };
+    if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
+    const auto t_l0 = std::chrono::steady_clock::now();
+    Loader L(p);
+    if (L.seekable() && G > 1) {
+      // plain binary file: every device's thread reads its own ranges (nothing is read twice, nothing is replicated)
+      L.finish(p.n_sites * p.n_ind * 24 != L.raw_size);  // the size check of the whole file, once
+      std::vector<std::thread> th;
+      for (uint64_t d = 0; d < G; d++)
+        th.emplace_back([&, d]() {
+          for (uint64_t k = d; k < n_parts; k += G) {
+            const uint64_t c0 = k * part, c1 = std::min(p.n_sites, c0 + part);
+            Loader Ld(p, c0);
+            Engine eng;
+            make_engine(eng, c1 - c0, (int)d);
+            Ld.load(eng, c1 - c0, c1 == p.n_sites);
+            Ld.finish(false);
+            compute_range(eng, c0, c1, d);
+          }
+        });
+      for (auto &t : th) t.join();
+    } else {
+      // a stream (gz text, gz binary, stdin) is read front to back by this thread; a range is computed by its device's
+      // thread while the next range is read into the next device
+      std::vector<std::thread> busy(G);
+      for (uint64_t k = 0; k < n_parts; k++) {
+        const uint64_t d = k % G, c0 = k * part, c1 = std::min(p.n_sites, c0 + part);
+        if (busy[d].joinable()) busy[d].join();  // the device's previous range has left it
+        Engine *eng = new Engine();
+        make_engine(*eng, c1 - c0, (int)d);
+        L.load(*eng, c1 - c0, c1 == p.n_sites);
+        busy[d] = std::thread([&, eng, c0, c1, d]() {
+          compute_range(*eng, c0, c1, d);
+          delete eng;
+        });
+      }
+      for (auto &t : busy) if (t.joinable()) t.join();
+      L.finish();
     }
-    L.finish();
+    const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_l0).count();
+    double t_dev = 0;
+    for (double v : dev_secs) t_dev = std::max(t_dev, v);
+    t_compute += t_dev;
     if (p.verbose >= 2)
-      fprintf(stderr, "> read + prepare + upload: %.3f s in %lu ranges (%.2f GB of prepared input in all)\n", t_load, n_parts,
-              (double)p.n_ind * p.n_sites * 24 / 1e9);
+      fprintf(stderr, "> read + prepare + upload + distances of %lu ranges on %lu device(s): %.3f s (%.2f GB of prepared input "
+              "in all; slowest device's kernels and copies %.3f s)\n", n_parts, G, t_all, (double)p.n_ind * p.n_sites * 24 / 1e9,
+              t_dev);
+    std::vector<double> &tot_sum = dev_sum[0];
+    std::vector<uint64_t> &tot_cnt = dev_cnt[0];
+    if (tot_sum.empty()) { tot_sum.assign(n_mat * n_comb, 0.0); tot_cnt.assign(n_mat * n_comb, 0); }
+    for (uint64_t d = 1; d < G; d++)
+      if (!dev_sum[d].empty())
+        for (uint64_t k = 0; k < n_mat * n_comb; k++) { tot_sum[k] += dev_sum[d][k]; tot_cnt[k] += dev_cnt[d][k]; }
     for (uint64_t rep = 0; rep < n_mat; rep++)
       emit(rep, &tot_sum[rep * n_comb], &tot_cnt[rep * n_comb],
            rep && !maps_kept.empty() ? &maps_kept[(rep - 1) * n_blocks] : nullptr, n_blocks);
   } else {
-  Engines eng;
-  make_engines(eng, p.n_sites, p.n_gpus);
+  Engine eng;
+  make_engine(eng, p.n_sites, 0);
   if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
   const auto t_load0 = std::chrono::steady_clock::now();
-  load_and_upload(p, eng);
+  {
+    Loader L(p);
+    L.load(eng, p.n_sites, true);
+    L.finish();
+  }
   const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
   if (p.verbose >= 2)
-    fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident per device)\n", t_load,
+    fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident on the device)\n", t_load,
             (double)p.n_ind * p.n_sites * 24 / 1e9);
 
   // Matrices go to the engine in batches: the first batch is the full-data matrix plus the first replicates
@@ -850,30 +906,22 @@ int main(int argc, char **argv) {
   std::vector<uint64_t> cnt, block_maps;
   uint64_t n_sites = p.n_sites;
 
-  // all engines, one host thread each; shards are disjoint, so merging is x + 0
   auto run_all = [&](const uint64_t *maps, uint32_t n_rep, bool with_full, uint64_t n_blocks) {
     const uint64_t n_mat = n_rep + (with_full ? 1 : 0);
     sum.assign(n_mat * n_comb, 0.0);
     cnt.assign(n_mat * n_comb, 0);
-    auto run_one = [&](size_t r, double *s, uint64_t *c) {
-      return with_full ? ngd_run_job(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c)
-                       : ngd_run_batch(eng.e[r], maps, n_rep, n_blocks, p.boot_block_size, s, c);
-    };
-    if (eng.e.size() == 1) {
-      int rc = run_one(0, sum.data(), cnt.data());
-      if (rc) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rc);
+    if (n_rep && n_blocks == 0) {
+      // fewer sites than one bootstrap block: the reference truncates the replicates to 0 sites (ngsDist.cpp:236),
+      // visits none and prints 0/0; the full data set is still a plain run
+      if (with_full) {
+        int rc = ngd_run(eng.h, nullptr, 0, 0, sum.data(), cnt.data());
+        if (rc) die_engine("ngd_run", rc);
+      }
       return;
     }
-    std::vector<std::vector<double>> ps(eng.e.size(), std::vector<double>(n_mat * n_comb));
-    std::vector<std::vector<uint64_t>> pc(eng.e.size(), std::vector<uint64_t>(n_mat * n_comb));
-    std::vector<int> rcs(eng.e.size(), 0);
-    std::vector<std::thread> th;
-    for (size_t r = 0; r < eng.e.size(); r++)
-      th.emplace_back([&, r]() { rcs[r] = run_one(r, ps[r].data(), pc[r].data()); });
-    for (auto &t : th) t.join();
-    for (size_t r = 0; r < eng.e.size(); r++) if (rcs[r]) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rcs[r]);
-    for (size_t r = 0; r < eng.e.size(); r++)
-      for (uint64_t k = 0; k < n_mat * n_comb; k++) { sum[k] += ps[r][k]; cnt[k] += pc[r][k]; }
+    int rc = with_full ? ngd_run_job(eng.h, maps, n_rep, n_blocks, p.boot_block_size, sum.data(), cnt.data())
+                       : ngd_run_batch(eng.h, maps, n_rep, n_blocks, p.boot_block_size, sum.data(), cnt.data());
+    if (rc) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rc);
   };
 
   for (uint64_t rep = 0; rep <= p.n_boot_rep;) {

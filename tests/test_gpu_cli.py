@@ -57,7 +57,7 @@ def test_every_kernel_prints_the_same_bytes(tmp_path):
     base = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200]
     for k in ("stream", "mfma"):
         assert cli(tmp_path, *base, "--indep_geno", "--evol_model", 0, "--kernel", k) == golden("t_gl_I0.dist")
-    for k in ("em_fast", "em_faithful"):
+    for k in ("em_table", "em_fast", "em_faithful"):
         assert cli(tmp_path, *base, "--evol_model", 2, "--kernel", k) == golden("t_gl_EM2.dist")
 
 
@@ -206,20 +206,51 @@ def test_text_input_errors(tmp_path):
     assert r.returncode == 255 and b"Genotypes must be coded as {-1,0,1,2}" in r.stderr
 
 
-def test_multi_gpu_merge_path_on_one_device(tmp_path, monkeypatch):
-    """--n_gpus 3 with every shard on device 0: three engines, pair tiles dealt over them, sums merged on
-    the host -- the same bytes as one engine."""
-    monkeypatch.setenv("NGD_HOST_SAME_DEVICE", "1")
-    n_ind, n_sites = 300, 500
+def cells(text):
+    return np.array([float(x) for ln in text.splitlines() if "\t" in ln for x in ln.split("\t")[1:]])
+
+
+def test_multi_gpu_site_ranges_on_one_device(tmp_path):
+    """--n_gpus 3 --same_device: the site axis in three ranges, each read, held and computed by its own engine and
+    host thread, sums added.  Called genotypes (every term dyadic): the same bytes as one engine -- through the
+    stream reader (gz text: ranges are read front to back and computed while the next is read) and through the
+    binary file (every device's thread reads its own range), bootstrap and --pairwise_del included.  GL data
+    (indep and EM paths): equal to 1e-9."""
+    path, lpath, labels = _testA_like(tmp_path)
+    base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345]
+    for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--n_boot_rep", 2, "--n_threads", 3]):
+        one = cli(tmp_path, *base, *extra, name="one.dist")
+        r = subprocess.run([BIN] + [str(a) for a in base + extra] + ["--n_gpus", "3", "--same_device", "--out",
+                                                                      str(tmp_path / "three.dist"), "--verbose", "1"],
+                           capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+        assert b"Site axis split over 3 devices: 3 ranges" in r.stderr
+        assert open(str(tmp_path / "three.dist")).read() == one
+    n_ind, n_sites = 300, 2000
     raw = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.1).transpose(1, 0, 2).copy()
-    path = tmp_path / "g.bin"
-    raw.tofile(str(path))
-    base = ["--geno", path, "--probs", "--n_ind", n_ind, "--n_sites", n_sites]
+    gl = tmp_path / "g.bin"
+    raw.tofile(str(gl))
+    base = ["--geno", gl, "--probs", "--n_ind", n_ind, "--n_sites", n_sites]
+    # called on the host from the binary GLs: dyadic terms again -> identical bytes from parallel range readers
+    called = ["--call_geno", "--n_boot_rep", "2", "--boot_block_size", "20", "--seed", "3"]
+    assert cli(tmp_path, *base, *called, "--n_gpus", 4, "--same_device", name="four.dist") == cli(tmp_path, *base, *called)
     for extra in (["--indep_geno", "--pairwise_del"], ["--evol_model", "2"],
                   ["--indep_geno", "--n_boot_rep", "2", "--boot_block_size", "20", "--seed", "3"]):
-        one = cli(tmp_path, *base, *extra, name="one.dist")
-        three = cli(tmp_path, *base, *extra, "--n_gpus", 3, name="three.dist")
-        assert one == three
+        a = cells(cli(tmp_path, *base, *extra, name="one.dist"))
+        b = cells(cli(tmp_path, *base, *extra, "--n_gpus", 3, "--same_device", name="three.dist"))
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-12)
+
+
+def test_fewer_sites_than_one_bootstrap_block(tmp_path):
+    """--n_boot_rep with n_sites < --boot_block_size: the reference truncates the replicates to 0 sites
+    (ngsDist.cpp:236), visits none and prints 0/0 cells after the full-data matrix"""
+    raw = np.fromfile(T_GL, dtype=np.float64)
+    p = O.prep_binary(raw, 6, 200)
+    exp = O.run_reference_flow(p, evol_model=1, indep_geno=True, n_boot_rep=2, boot_block_size=500, seed=1)
+    assert "nan" in exp
+    for extra in ([], ["--n_gpus", 2, "--same_device"]):
+        assert cli(tmp_path, "--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno", "--n_boot_rep", 2,
+                   "--boot_block_size", 500, "--seed", 1, *extra) == exp
 
 
 def test_bench_line_contract(tmp_path):
@@ -273,31 +304,27 @@ def test_binary_input_size_errors_and_gz_binary(tmp_path):
     assert got == exp
 
 
-def test_data_set_larger_than_the_device_goes_through_in_ranges(tmp_path, monkeypatch):
-    """NGD_HOST_MAX_BYTES below the data set's footprint: the host sends ranges of sites through one engine and
-    adds the per-range (sum, cnt).  Called genotypes (every term dyadic): byte-identical to the one-engine run,
-    bootstrap replicates, --pairwise_del and text input included; GL data on the EM path: equal to 1e-9."""
+def test_data_set_larger_than_the_device_goes_through_in_ranges(tmp_path):
+    """--max_device_bytes below the data set's footprint: the host sends ranges of sites through the device one
+    after the other and adds the per-range (sum, cnt).  Called genotypes (every term dyadic): byte-identical to the
+    one-engine run, bootstrap replicates, --pairwise_del and text input included; GL data on the EM path: equal to 1e-9."""
     path, lpath, labels = _testA_like(tmp_path)
     base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345]
     # footprint model of the host: 512 MiB + slabs + 64 B per pair fixed, ~6.2 KB per site at 24 individuals
     small = str((512 << 20) + 256 * 128 * 128 * 8 + 276 * 64 + 6200 * 2600)
     for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--n_boot_rep", 2, "--n_threads", 3]):
-        monkeypatch.delenv("NGD_HOST_MAX_BYTES", raising=False)
         whole = cli(tmp_path, *base, *extra)
-        monkeypatch.setenv("NGD_HOST_MAX_BYTES", small)
-        r = subprocess.run([BIN] + [str(a) for a in base + extra] + ["--out", str(tmp_path / "parts.dist"), "--verbose", "1"],
+        r = subprocess.run([BIN] + [str(a) for a in base + extra] + ["--max_device_bytes", small, "--out",
+                                                                      str(tmp_path / "parts.dist"), "--verbose", "1"],
                            capture_output=True)
         assert r.returncode == 0, r.stderr.decode()
         assert b"larger than the device budget" in r.stderr and b" 4 ranges" in r.stderr
         assert open(str(tmp_path / "parts.dist")).read() == whole
-    # binary GL input, EM path, bootstrap with 16-site blocks: numerically equal
+    # binary GL input, EM path, bootstrap with 16-site blocks: numerically equal; also two devices that are too small
     gl = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--n_boot_rep", 2, "--boot_block_size", 16, "--seed", 5]
-    monkeypatch.delenv("NGD_HOST_MAX_BYTES", raising=False)
     whole = cli(tmp_path, *gl)
-    monkeypatch.setenv("NGD_HOST_MAX_BYTES", str((512 << 20) + 256 * 128 * 128 * 8 + 15 * 64 + 3200 * 70))
-    parts = cli(tmp_path, *gl, name="p2.dist")
-
-    def cells(t):
-        return np.array([float(x) for ln in t.splitlines() if "\t" in ln for x in ln.split("\t")[1:]])
-    a, b = cells(whole), cells(parts)
-    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-10)
+    tiny = str((512 << 20) + 256 * 128 * 128 * 8 + 15 * 64 + 3200 * 70)
+    for extra in ([], ["--n_gpus", 2, "--same_device"]):
+        parts = cli(tmp_path, *gl, "--max_device_bytes", tiny, *extra, name="p2.dist")
+        a, b = cells(whole), cells(parts)
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-10)
