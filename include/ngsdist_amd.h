@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 1
+#define NGD_ABI_VERSION 2
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
@@ -64,7 +64,14 @@ typedef struct ngd_config {
   int32_t kernel;       /* NGD_KERNEL_*                                       */
   uint32_t shard_rank;  /* this engine computes the pair tiles that            */
   uint32_t shard_world; /*   ngd_shard_of_pair() gives it; 0/1 = everything   */
-  uint32_t reserved[6]; /* must be zero                                       */
+  /* Launch geometry; 0 = the measured defaults, which is what a host wants.  They change
+   * speed only, never results beyond the order of additions over site slices. */
+  uint32_t variant;      /* NGD_KERNEL_EM_TABLE: workgroup shape 0..3 (accum_em_table.hip)            */
+  uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8)  */
+  uint32_t wg_target;    /* workgroups wanted per launch, from which n_slices is derived when it is 0 */
+  uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 = always issue only the MFMA tiles a block   */
+                         /* needs (auto: when n_ind padded to 128 is at most 384)                      */
+  uint32_t reserved[2];  /* must be zero                                                               */
 } ngd_config;
 
 /* Per-run device timings (HIP events on the engine's stream). */
@@ -206,6 +213,17 @@ int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep
  * recomputed automatically when either changes).  This forgets them, so that a
  * benchmark can charge the partial-sum pass to every timed step. */
 int ngd_drop_caches(ngd_engine *e);
+
+/* Plan selection for the replicate loop, per engine and changeable between runs (defaults in brackets).  The engine
+ * picks the cheapest plan that applies by itself; these exist to pin one for a comparison or to bound memory.
+ * Every plan returns the same counts and sums equal to rounding ("Plans"). */
+#define NGD_OPT_BOOT_PARTIALS 1  /* [1] bootstrap replicates from per-block partial (sum, cnt): 0 never, 1 when they */
+                                 /*     fit and pay for their allocation, 2 allocate even a large slab at once       */
+#define NGD_OPT_BOOT_MAX_BYTES 2 /* [0 = 85 % of free device memory] budget of those partials                        */
+#define NGD_OPT_BOOT_WG 3        /* [4096] workgroups wanted in the pass that fills them                             */
+#define NGD_OPT_BOOT_UNALIGNED 4 /* [1] MFMA path: partials also for block sizes that are not multiples of 4 sites   */
+#define NGD_OPT_EM_BATCH 5       /* [1] per-pair EM kernels without partials: up to 16 matrices per accumulation pass */
+int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
 /* Work done by the table-driven EM kernel (NGD_KERNEL_EM_TABLE) in the last run, for roofline accounting: the number

@@ -23,7 +23,11 @@ class NgdConfig(C.Structure):
         ("kernel", C.c_int32),
         ("shard_rank", C.c_uint32),
         ("shard_world", C.c_uint32),
-        ("reserved", C.c_uint32 * 6),
+        ("variant", C.c_uint32),
+        ("n_slices", C.c_uint32),
+        ("wg_target", C.c_uint32),
+        ("exact_shapes", C.c_uint32),
+        ("reserved", C.c_uint32 * 2),
     ]
 
 
@@ -49,7 +53,7 @@ EXPORTS = [
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
     "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
-    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_drop_caches", "ngd_last_timing", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
+    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair",
 ]
 
@@ -103,6 +107,7 @@ def load():
     L.ngd_run_job_device.argtypes = [vp, u64p, C.c_uint32, u64, u64, vp, vp]
     L.ngd_run_mult_batch_device.argtypes = [vp, u32p, C.c_uint32, u64, u64, vp, vp]
     L.ngd_drop_caches.argtypes = [vp]
+    L.ngd_set_option.argtypes = [vp, C.c_int, u64]
     L.ngd_last_timing.argtypes = [vp, C.POINTER(NgdTiming)]
     L.ngd_last_em_work.argtypes = [vp, u64p, u64p]
     L.ngd_finish.argtypes = [dp, u64p, u64, u64, u64, dp]

@@ -24,8 +24,6 @@
 // the same time, which keeps the slice's operand panel in that XCD's L2.
 // Slices are written as slabs and summed in fixed order by reduce.hip
 // (deterministic; no floating-point atomics).
-#include <cstdlib>
-
 #include "ngd_internal.h"
 
 namespace {
@@ -302,25 +300,19 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab) {
   if (!n_wg) return;
   // n_ks is a multiple of 8 (see the deal in the kernel)
-  static const int variant = [] {
-    const char *v = getenv("NGD_MFMA_VARIANT");
-    return v && *v ? atoi(v) : 0;
-  }();
   // EXACT: one job per (single-wavefront) workgroup -- jobs of different shapes last differently, and a
   // wavefront that is done should not wait for three siblings before its slot is handed on
 #define NGD_MFMA(W, D, P, X)                                                                                    \
   hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
                      n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab)
-  // variant 0 (default): no in-wave run-ahead, 3 wavefronts per SIMD -- measured fastest
-  // (profiles/r01_*): the third wavefront covers the others' load phases.
-  // variant 1: 4-deep register ring, 2 wavefronts per SIMD.
+  // No in-wave run-ahead (DEPTH 1), 3 wavefronts per SIMD: the third wavefront covers the others' load phases.
+  // Measured against a 4-deep register ring at 2 wavefronts per SIMD (56.0 vs 51.0 ms on the same job layout) and
+  // against LDS-staged operand panels (tools/experiments/accum_mfma_lds.hip; profiles/r01_cfg3_mfma_*): both lose.
   // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
   if (exact_shapes) {
     if (d_ws) NGD_MFMA(true, 1, 3, true); else NGD_MFMA(false, 1, 3, true);
-  } else if (d_ws) {
-    if (variant == 1) NGD_MFMA(true, 4, 2, false); else NGD_MFMA(true, 1, 3, false);
   } else {
-    if (variant == 1) NGD_MFMA(false, 4, 2, false); else NGD_MFMA(false, 1, 3, false);
+    if (d_ws) NGD_MFMA(true, 1, 3, false); else NGD_MFMA(false, 1, 3, false);
   }
 #undef NGD_MFMA
 }

@@ -97,6 +97,8 @@ struct ngd_engine {
   bool committed = false;
   uint64_t dev_bytes = 0;
   ngd_timing timing{};
+  // plan options (ngd_set_option)
+  uint64_t opt_boot_partials = 1, opt_boot_max_bytes = 0, opt_boot_wg = 4096, opt_boot_unaligned = 1, opt_em_batch = 1;
 };
 
 template <typename T>
@@ -119,11 +121,6 @@ static int ensure_cap(ngd_engine *e, T **p, uint64_t *cap, uint64_t need) {
   if (rc) return rc;
   *cap = need;
   return NGD_OK;
-}
-
-static uint64_t env_u64(const char *name, uint64_t dflt) {
-  const char *v = getenv(name);
-  return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
 }
 
 extern "C" {
@@ -187,6 +184,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (cfg->n_ind > 60000) return fail(NGD_E_INVALID, "ngd_create: n_ind > 60000 not supported");
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
+  if (cfg->exact_shapes > 2) return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never) or 2 (always)");
+  if (cfg->variant > 3) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
   const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
   if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
 
@@ -268,7 +267,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // job list of the MFMA kernel (ngd_job, units of 16 individuals).
   std::vector<ngd_job> jobs;
   const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);  // groups that hold at least one individual
-  e->exact_shapes = env_u64("NGD_MFMA_EXACT", g.n_pad <= env_u64("NGD_MFMA_EXACT_MAX_PAD", 384) ? 1 : 0) != 0;
+  e->exact_shapes = cfg->exact_shapes ? cfg->exact_shapes == 2 : g.n_pad <= 384;
   if (e->exact_shapes) {
     // blocks of up to 4 x 4 groups over the valid groups only; the last block row / column is narrower,
     // blocks on the diagonal are triangular.  Most expensive first, four to a workgroup.
@@ -374,10 +373,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
 
   // ---- split over the site axis: slices -> slabs, reduced in fixed order ----
   if (kernel == NGD_KERNEL_MFMA) {
-    uint64_t want = env_u64("NGD_MFMA_WG", 8192);
+    uint64_t want = cfg->wg_target ? cfg->wg_target : 8192;
     const uint32_t wg_per_slice = std::max(1u, e->n_wg);
     uint64_t ks = (want * (e->exact_shapes ? 4 : 1) + wg_per_slice - 1) / wg_per_slice;  // EXACT: 1-wave workgroups
-    uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / env_u64("NGD_MFMA_MIN_KG", 128));
+    uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / 128);  // at least 128 k-groups per slice
     ks = std::min(ks, max_ks);
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     {
@@ -398,9 +397,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
         const double waste = std::ceil(rounds - 1e-9) / rounds + 1e-4 * std::fabs((double)c - (double)ks) / (double)ks;
         if (waste < best) { best = waste; best_ks = c; }
       }
-      if (env_u64("NGD_MFMA_ROUNDS", 1)) ks = best_ks;
+      ks = best_ks;
     }
-    ks = env_u64("NGD_MFMA_KS", ks);
+    if (cfg->n_slices) ks = cfg->n_slices;
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
@@ -408,22 +407,22 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } else if (kernel == NGD_KERNEL_EM_TABLE) {
     // 64 x 64 tiles x slices of sites; a workgroup works a site in ~10 us, so slices of a few thousand sites keep
     // the tail of the launch short without making the slab large
-    e->em_shape = (int)env_u64("NGD_EMT_SHAPE", 0);
-    uint64_t want = env_u64("NGD_EMT_WG", 16384);
+    e->em_shape = (int)cfg->variant;
+    uint64_t want = cfg->wg_target ? cfg->wg_target : 16384;
     uint64_t ks = e->n_tiles64 ? (want + e->n_tiles64 - 1) / e->n_tiles64 : 1;
     uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 64);
     ks = std::min(ks, max_ks);
-    ks = std::max<uint64_t>(1, env_u64("NGD_EM_KS", ks));
+    if (cfg->n_slices) ks = cfg->n_slices;
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
     TRY(dev_alloc(e, &e->d_emcnt, 2, true));
   } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
-    uint64_t want = env_u64("NGD_EM_WG", 4096);
+    uint64_t want = cfg->wg_target ? cfg->wg_target : 4096;
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
     uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 256);
     ks = std::min(ks, max_ks);
-    ks = std::max<uint64_t>(1, env_u64("NGD_EM_KS", ks));
+    if (cfg->n_slices) ks = cfg->n_slices;
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
@@ -581,10 +580,7 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
   const ngd_geom &g = e->g;
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
-      if (env_u64("NGD_MFMA_VARIANT", 0) >= 2)
-        ngd_launch_accum_mfma_lds(e->st, g, e->PA, e->QB, w, e->d_tiles, e->n_tiles, n_ks, per_slice, kg_lim, slab);
-      else
-        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
+      ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
                               (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
                               kg_lim, k_per_slice, w_stride, slab);
       break;
@@ -629,7 +625,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
   uint32_t n_list = 0;
-  const bool list_pass = mult && e->kernel == NGD_KERNEL_MFMA && env_u64("NGD_MFMA_VARIANT", 0) < 2;
+  const bool list_pass = mult && e->kernel == NGD_KERNEL_MFMA;
   HIPCHK(hipEventRecord(e->ev[0], e->st));
   if (mult) {
     n_eff = n_blocks * block_size;
@@ -701,12 +697,11 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   const bool mfma = e->kernel == NGD_KERNEL_MFMA;
   const bool pdel = e->cfg.pairwise_del != 0;
   *feasible = false;
-  if (e->kernel == NGD_KERNEL_STREAM || !env_u64("NGD_BOOT_PARTIALS", 1)) return NGD_OK;
-  if (mfma && env_u64("NGD_MFMA_VARIANT", 0) >= 2) return NGD_OK;
+  if (e->kernel == NGD_KERNEL_STREAM || !e->opt_boot_partials) return NGD_OK;
   // MFMA slices are whole k-groups of 4 contraction indices; a block of B sites is 3 B of them.  Blocks that are not
   // whole k-groups become slices of every k-group they touch, the shared first / last k-group masked per slice.
   const bool unaligned = mfma && block_size % 4 != 0;
-  if (unaligned && !env_u64("NGD_BOOT_UNALIGNED", 1)) return NGD_OK;
+  if (unaligned && !e->opt_boot_unaligned) return NGD_OK;
   if (n_blocks >= (1ull << 31)) return NGD_OK;
   // split large blocks so that there are enough workgroups; slices of one block share its weight
   const uint64_t unit = mfma ? 3 * block_size / 4 : block_size;  // k-groups or sites per block
@@ -718,7 +713,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   } else {
     const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1))
                                   : e->kernel == NGD_KERNEL_EM_TABLE ? e->n_tiles64 : e->n_tiles16;
-    const uint64_t want = env_u64("NGD_BOOT_WG", 4096);
+    const uint64_t want = e->opt_boot_wg;
     while (!unaligned && tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 &&
            unit / (sub * 2) >= 32)
       sub *= 2;
@@ -735,12 +730,12 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     const uint64_t have = e->slab_boot_elems * 8 + e->cnt_boot_elems * 4;
     // default budget: most of what the device has left -- one pass over a slab of tens of GB still beats
     // hundreds of accumulation passes
-    const uint64_t budget = env_u64("NGD_BOOT_MAX_BYTES", (uint64_t)((free_b + have) / 100 * 85));
+    const uint64_t budget = e->opt_boot_max_bytes ? e->opt_boot_max_bytes : (uint64_t)((free_b + have) / 100 * 85);
     if (need > budget) return NGD_OK;
     if ((elems > e->slab_boot_elems || c_elems > e->cnt_boot_elems) && need + (1ull << 30) > free_b + have)
       return NGD_OK;
     const double alloc_ms = need > have ? (double)(need - have) * 12e-9 : 0.0;
-    if (alloc_ms > 20.0 && env_u64("NGD_BOOT_PARTIALS", 1) < 2) {
+    if (alloc_ms > 20.0 && e->opt_boot_partials < 2) {
       // what this call costs without the partials: a list-driven pass per replicate (MFMA, ~3/4 of a pass)
       // or a batch pass per 16 replicates (EM); rates are the measured ones of DESIGN.md section 6
       const double ps = (double)e->n_owned_pairs * (double)n_eff;
@@ -976,7 +971,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   // 2. EM kernels: many matrices per accumulation pass.  The faithful form keeps matrix 0 on the plain pass,
   //    whose accumulation is the reference's term by term.
   const bool em = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
-  if (em && n_rep + lead >= 2 && env_u64("NGD_EM_BATCH", 1)) {
+  if (em && n_rep + lead >= 2 && e->opt_em_batch) {
     const bool fold = lead && e->kernel == NGD_KERNEL_EM_FAST;
     if (lead && !fold) {
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
@@ -1095,6 +1090,25 @@ int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint6
   rc = run_impl(e, block_maps, nullptr, n_rep, n_rep != 0, n_blocks, block_size, e->d_bsum, e->d_bcnt);
   if (rc) return rc;
   return copy_out(e, n_rep + 1, e->d_bsum, e->d_bcnt, sum, cnt);
+}
+
+int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_set_option: null engine");
+  switch (option) {
+    case NGD_OPT_BOOT_PARTIALS:
+      if (value > 2) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_BOOT_PARTIALS is 0, 1 or 2");
+      e->opt_boot_partials = value;
+      break;
+    case NGD_OPT_BOOT_MAX_BYTES: e->opt_boot_max_bytes = value; break;
+    case NGD_OPT_BOOT_WG:
+      if (!value) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_BOOT_WG must be positive");
+      e->opt_boot_wg = value;
+      break;
+    case NGD_OPT_BOOT_UNALIGNED: e->opt_boot_unaligned = value != 0; break;
+    case NGD_OPT_EM_BATCH: e->opt_em_batch = value != 0; break;
+    default: return fail(NGD_E_INVALID, "ngd_set_option: unknown option");
+  }
+  return NGD_OK;
 }
 
 int ngd_drop_caches(ngd_engine *e) {

@@ -109,11 +109,6 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab);
 
-// accum_mfma_lds.hip : same contraction, operand panels staged per workgroup in LDS by LDS-DMA
-void ngd_launch_accum_mfma_lds(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
-                               const uint32_t *d_ws, const ngd_tile *d_tiles, uint32_t n_tiles,
-                               uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff, double *slab);
-
 // accum_em.hip : per-site EM, one thread per pair of a 16x16 tile
 void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                          uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,

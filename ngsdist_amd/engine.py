@@ -13,6 +13,8 @@ import numpy as np
 from . import _lib
 
 KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4, "em_table": 5}
+# NGD_OPT_* of include/ngsdist_amd.h
+OPTIONS = {"boot_partials": 1, "boot_max_bytes": 2, "boot_wg": 3, "boot_unaligned": 4, "em_batch": 5}
 
 # parse_args.cpp:25-27
 DEFAULT_SCORE = (0.0, 0.5, 1.0, 0.5, 0.0, 0.5, 1.0, 0.5, 0.0)
@@ -49,7 +51,7 @@ class Engine:
     gen_dist() over every pair this engine's shard owns."""
 
     def __init__(self, n_ind, n_sites, score=None, pairwise_del=False, indep_geno=True, kernel="auto",
-                 device=-1, shard_rank=0, shard_world=1):
+                 device=-1, shard_rank=0, shard_world=1, variant=0, n_slices=0, wg_target=0, exact_shapes=0):
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.NgdConfig()
@@ -60,6 +62,8 @@ class Engine:
         cfg.pairwise_del, cfg.indep_geno = int(bool(pairwise_del)), int(bool(indep_geno))
         cfg.device, cfg.kernel = int(device), KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
+        # launch geometry, 0 = the engine's defaults (ngd_config)
+        cfg.variant, cfg.n_slices, cfg.wg_target, cfg.exact_shapes = int(variant), int(n_slices), int(wg_target), int(exact_shapes)
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
         self.n_pairs = n_pairs(self.n_ind)
         _check(self._L.ngd_create(C.byref(cfg), C.byref(self._h)))
@@ -195,6 +199,12 @@ class Engine:
         """Results written to caller-owned device buffers (raw addresses)."""
         ptr, nb, bs, keep = self._map_args(block_map, block_size)
         _check(self._L.ngd_run_device(self._h, ptr, nb, bs, C.c_void_p(d_sum_ptr), C.c_void_p(d_cnt_ptr)))
+
+    def set_option(self, name, value):
+        """plan selection for the replicate loop (ngd_set_option): boot_partials, boot_max_bytes, boot_wg, boot_unaligned,
+        em_batch"""
+        _check(self._L.ngd_set_option(self._h, OPTIONS[name], int(value)))
+        return self
 
     def drop_caches(self):
         """forget the bootstrap block partial sums (benchmarks: charge them to every step)"""

@@ -75,12 +75,11 @@ def test_cfg3_block_additivity_and_permutation_invariance(cfg3_mfma):
     s_hi, _ = e.run(hi, B)
     assert rel(s_lo + s_hi, 2 * full) < 1e-12
     # and the one-pass-per-replicate path agrees with the partial-sum path
-    import os
-    os.environ["NGD_BOOT_PARTIALS"] = "0"
+    e.set_option("boot_partials", 0)
     try:
         s_w, _ = e.run(perm, B)
     finally:
-        os.environ.pop("NGD_BOOT_PARTIALS")
+        e.set_option("boot_partials", 1)
     assert rel(s_w, s_perm) < 1e-12
 
 

@@ -151,9 +151,9 @@ def test_bootstrap_replicates(kernel, block_size):
 
 @pytest.mark.parametrize("kernel,block_size", [("mfma", 8), ("mfma", 100), ("mfma", 7), ("mfma", 1), ("mfma", 10),
                                                ("em_fast", 5), ("em_faithful", 12), ("em_table", 5), ("em_table", 32)])
-def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkeypatch):
+def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size):
     """Replicates served from per-block partial sums (default) vs. one weighted accumulation
-    pass per replicate (NGD_BOOT_PARTIALS=0): same counts, sums within rounding, both within
+    pass per replicate (option boot_partials = 0): same counts, sums within rounding, both within
     tolerance of the oracle; changing the block size re-derives the partial sums."""
     n_ind, n_sites = 40, 2003
     indep = kernel == "mfma"
@@ -165,17 +165,17 @@ def test_bootstrap_block_partials_equal_weighted_pass(kernel, block_size, monkey
             n_eff = n_sites - n_sites % B
             for rep in range(2):
                 bm = rng.block_map(n_eff // B)
-                monkeypatch.setenv("NGD_BOOT_PARTIALS", "1")
+                e.set_option("boot_partials", 1)
                 s1, c1 = e.run(bm, B)
                 t1 = e.timing()
-                monkeypatch.setenv("NGD_BOOT_PARTIALS", "0")
+                e.set_option("boot_partials", 0)
                 s0, c0 = e.run(bm, B)
                 so, co = O.all_pairs(p, pairwise_del=True, indep_geno=indep, site_src=O.boot_site_src(bm, B),
                                      n_sites=n_eff, n_threads=8)
                 assert np.array_equal(c1, co) and np.array_equal(c0, co)
                 assert rel_err(s1, so) < RTOL and rel_err(s0, so) < RTOL
                 assert t1["launches"] == (1 if rep == 0 else 0)  # second replicate re-uses the partial sums
-        monkeypatch.setenv("NGD_BOOT_PARTIALS", "1")
+        e.set_option("boot_partials", 1)
         e.drop_caches()
         e.run(bm, B)
         assert e.timing()["launches"] == 1
@@ -238,12 +238,11 @@ def test_bootstrap_batch_called_genotypes_bit_exact():
     ("em_faithful", 3, True, False), ("em_faithful", 12, False, True),
     ("em_table", 5, True, True), ("em_table", 1, True, False), ("em_table", 7, False, False)])
 @pytest.mark.parametrize("n_rep", [0, 1, 5, 20])
-def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep, monkeypatch):
+def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
     """ngd_run_job: matrix 0 = ngd_run(NULL) (counts exact, sums to rounding; bit-identical where the plan keeps the
     plain pass), replicates bit-identical to ngd_run(block_map); whatever plan the engine picks: per-block partials
     with the all-ones row (mfma 8 / em with partials on), the EM batch pass (partials off: what large data sets with
     small blocks get), one list-driven weighted pass per replicate (mfma 7, 1), the streaming kernel."""
-    monkeypatch.setenv("NGD_BOOT_PARTIALS", "1" if partials else "0")
     n_ind, n_sites = 21, 1203
     indep = kernel in INDEP_KERNELS
     p = O.synth_indmajor(31, n_ind, n_sites, miss_frac=0.2)
@@ -251,6 +250,7 @@ def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep, monkey
     n_eff = n_sites - n_sites % block_size
     maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)]) if n_rep else None
     with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
+        e.set_option("boot_partials", 1 if partials else 0)
         e.upload_ind_major(p).commit()
         S, Cn = e.run_job(maps, block_size)
         assert S.shape == (n_rep + 1, e.n_pairs)
@@ -489,39 +489,36 @@ def test_site_shards_bit_exact_for_called_genotypes_and_synth_ranges():
 
 def test_random_shapes_flags_and_plans():
     """a fixed-seed sweep over odd shapes: n_ind / n_sites around the padding edges (16, 64, 128), every kernel,
-    random flags, block sizes and replicate counts, partials on/off -- ngd_run_job against the oracle."""
+    random flags, block sizes and replicate counts, partials on/off, EM batch pass on/off, launch geometry left to the
+    engine or forced (slice count, exact block shapes) -- ngd_run_job against the oracle."""
     rng = np.random.default_rng(20260)
     kernels = INDEP_KERNELS + EM_KERNELS
-    old = os.environ.get("NGD_BOOT_PARTIALS")
-    try:
-        for case in range(28):
-            kernel = kernels[case % 4]
-            indep = kernel in INDEP_KERNELS
-            n_ind = int(rng.choice([2, 3, 15, 16, 17, 31, 33, 63, 65, 127, 129, 140]))
-            n_sites = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 257, 1000, 1025]))
-            pdel = bool(rng.integers(0, 2))
-            miss = float(rng.choice([0.0, 0.3]))
-            B = int(rng.choice([1, 2, 3, 4, 8, 12, 50]))
-            B = min(B, n_sites)
-            n_rep = int(rng.choice([0, 1, 2, 17]))
-            os.environ["NGD_BOOT_PARTIALS"] = str(int(rng.integers(0, 2)))
-            score = O.score_matrix(bool(rng.integers(0, 2)))
-            p = O.synth_indmajor(100 + case, n_ind, n_sites, miss_frac=miss)
-            n_eff = n_sites - n_sites % B
-            t = N().Taus(case)
-            maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
-            with N().Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
-                e.upload_ind_major(p).commit()
-                S, Cn = e.run_job(maps, B)
-            tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, os.environ["NGD_BOOT_PARTIALS"])
-            for m in sorted({0, n_rep}):
-                src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
-                so, co = O.all_pairs(p, score=score, pairwise_del=pdel, indep_geno=indep, site_src=src,
-                                     n_sites=n_sites if m == 0 else n_eff, n_threads=4)
-                assert np.array_equal(Cn[m], co), tag
-                assert rel_err(S[m], so) < RTOL, tag
-    finally:
-        if old is None:
-            os.environ.pop("NGD_BOOT_PARTIALS", None)
-        else:
-            os.environ["NGD_BOOT_PARTIALS"] = old
+    for case in range(35):
+        kernel = kernels[case % len(kernels)]
+        indep = kernel in INDEP_KERNELS
+        n_ind = int(rng.choice([2, 3, 15, 16, 17, 31, 33, 63, 65, 127, 129, 140]))
+        n_sites = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 257, 1000, 1025]))
+        pdel = bool(rng.integers(0, 2))
+        miss = float(rng.choice([0.0, 0.3]))
+        B = int(rng.choice([1, 2, 3, 4, 8, 12, 50]))
+        B = min(B, n_sites)
+        n_rep = int(rng.choice([0, 1, 2, 17]))
+        partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8])), exact_shapes=int(rng.integers(0, 3)) if kernel == "mfma" else 0,
+                    variant=int(rng.integers(0, 4)) if kernel == "em_table" else 0)
+        score = O.score_matrix(bool(rng.integers(0, 2)))
+        p = O.synth_indmajor(100 + case, n_ind, n_sites, miss_frac=miss)
+        n_eff = n_sites - n_sites % B
+        t = N().Taus(case)
+        maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
+        with N().Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
+            e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
+            e.upload_ind_major(p).commit()
+            S, Cn = e.run_job(maps, B)
+        tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, geom)
+        for m in sorted({0, n_rep}):
+            src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
+            so, co = O.all_pairs(p, score=score, pairwise_del=pdel, indep_geno=indep, site_src=src,
+                                 n_sites=n_sites if m == 0 else n_eff, n_threads=4)
+            assert np.array_equal(Cn[m], co), tag
+            assert rel_err(S[m], so) < RTOL, tag

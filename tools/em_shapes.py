@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/em_shapes.py [n_sites] -- times the EM kernels on the cfg 4 shape (1000 individuals, synthetic GLs):
-em_fast (one lane per pair) and the table-driven kernel in each workgroup shape (NGD_EMT_SHAPE), checks that
+em_fast (one lane per pair) and the table-driven kernel in each workgroup shape (ngd_config.variant), checks that
 they agree on every pair, prints ms per launch."""
 import os
 import sys
@@ -15,9 +15,7 @@ shapes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 
 n_ind = int(os.environ.get("N_IND", "1000"))
 ref = None
 for name, shape in [("em_fast", None)] + [("em_table", k) for k in shapes]:
-    if shape is not None:
-        os.environ["NGD_EMT_SHAPE"] = str(shape)
-    with N.Engine(n_ind, n_sites, indep_geno=False, kernel=name) as e:
+    with N.Engine(n_ind, n_sites, indep_geno=False, kernel=name, variant=shape or 0) as e:
         e.synth_fill(3)
         ms = []
         for it in range(3):

@@ -11,12 +11,11 @@ import ngsdist_amd as N  # noqa: E402
 
 n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 shape = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-os.environ["NGD_EMT_SHAPE"] = str(shape)
 n_ind = 1000
-nw = 8 if shape in (1, 3) else 4
+nw = 8 if shape in (0, 2) else 4
 rpw = 64 // nw
 names = ["loop", "wait GL loads", "site set-up", "build", "barrier 1", "scan", "barrier 2", "-"]
-with N.Engine(n_ind, n_sites, indep_geno=False, kernel="em_table") as e:
+with N.Engine(n_ind, n_sites, indep_geno=False, kernel="em_table", variant=shape) as e:
     e.synth_fill(3)
     s, c = e.run()
     ms = e.timing()["ms_accum"]

@@ -1,3 +1,7 @@
+// NOT BUILT: an experiment kept for the record (round 1), with its profiles under profiles/r01_cfg3_mfma_lds_*.
+// It was variant 2 / 3 of K1m and lost to the register-direct form of ngsdist_amd/csrc/accum_mfma.hip (51.6 / 54.5 ms
+// against 45.5 on cfg 3); to try it again add it to ngsdist_amd/csrc/Makefile and call ngd_launch_accum_mfma_lds().
+//
 // accum_mfma_lds.hip -- K1m, second form: the same FP64-MFMA contraction as
 // accum_mfma.hip (reference ngsDist.cpp:333-364, product branch of :353), with the
 // operand panels of a 128x128 pair tile staged ONCE per workgroup in LDS by
