@@ -382,7 +382,11 @@ def main():
                                 "frac": sb / PEAK_HBM_GBS,
                                 "algorithmic": "48 B per pair-site (north_star's one-wavefront-per-pair model)"}
         if kernel == "stream":
-            roof = dict(roof["stream_model"], kernel="k_accum_stream", traffic=None, ms_per_launch=acc_mean_ms)
+            # the 48 B model counts every re-read of an individual; all but one per tile of L2 are served on-die, so
+            # this figure can exceed 1 -- it is the north_star's roofline definition, not HBM utilisation (that is
+            # `traffic` / time, from the PMC pass)
+            roof = dict(roof["stream_model"], kernel="k_accum_stream", traffic=None, ms_per_launch=acc_mean_ms,
+                        note="algorithmic bytes (48 B per pair-site), mostly L2 / Infinity-Cache served; see traffic")
     else:
         # EM path: bound by FP64 VALU issue (HBM is irrelevant: 48 B per ~130 instructions).  The roof is the FP64 vector
         # pipe, 78.6 TFLOP/s = 39.3e12 lane-instruction slots/s x 2 flop (the same datapath and peak as FP64 MFMA,
@@ -413,15 +417,22 @@ def main():
             roof["per_pair_model"] = {"lane_instructions_per_pair_site": EMFAST_OPS_PER_PAIR_SITE,
                                       "frac": EMFAST_OPS_PER_PAIR_SITE * ps_launch / t_acc * 2 / 1e12 / PEAK_FP64_TFLOPS}
 
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
-    # figure is the one the last tools/profile.sh run of this same command left in profiles/
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the one
+    # the last tools/profile.sh run of this same command left in profiles/ -- accepted only if the kernel source it was
+    # measured on is the one this library was built from (sha256 recorded by tools/pmc_summary.py)
     try:
+        import hashlib
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, kernel))))
-        for kname, v in tj["per_launch"].items():
-            if "accum" in kname and "TRI" not in kname:
-                roof["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
-                roof["traffic_source"] = "profiles/traffic_%s_%s.json (%s)" % (args.workload, kernel, tj["source"])
-                break
+        src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
+        now = hashlib.sha256(open(os.path.join(ROOT, "ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+        if tj.get("kernel_source_sha16", {}).get(src) != now:
+            roof["traffic_stale"] = "profiles/traffic_%s_%s.json was measured on another version of %s" % (args.workload, kernel, src)
+        else:
+            for kname, v in tj["per_launch"].items():
+                if "accum" in kname:
+                    roof["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
+                    roof["traffic_source"] = "profiles/traffic_%s_%s.json (%s)" % (args.workload, kernel, tj["source"])
+                    break
     except Exception:
         pass
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_accum_em_batch(const double *__restrict
       // the site's score-weighted sum, exactly as the one-replicate kernel forms it (0 + c * 1 == c)
       const double c = FAST ? site_fast(g1, g2, sc, 0.0, 1.0) : site_faithful(g1, g2, sc, 0.0, 1.0, true);
 #pragma unroll
-      for (int r = 0; r < RB; r++) acc[r] = acc[r] + c * w[r];
+      for (int r = 0; r < RB; r++) acc[r] = w[r] != 0.0 ? acc[r] + c * w[r] : acc[r];  // not drawn: adds nothing, NaN included
     }
   }
 #pragma unroll

@@ -19,7 +19,7 @@ namespace {
 // "gsl v1.15") that is not under /root/reference.  Algorithm restated from its
 // published description (L'Ecuyer 1996 combined Tausworthe, three components,
 // seeding by the 69069 LCG, six warm-up draws); pinned by GSL's own known
-// answer in tests/test_host_abi.py (seed 1, 10000th output = 2733957125).
+// answer in tests/test_abi.py (seed 1, 10000th output = 2733957125).
 inline uint32_t taus_step(uint32_t s, int a, int b, uint32_t c, int d) {
   return ((s & c) << d) ^ (((s << a) ^ s) >> b);
 }

@@ -70,12 +70,18 @@ __global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ sl
 #pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)(ks + u) * w_stride + r], v[u], acc[r]);
+        for (int r = 0; r < RB; r++) {  // a block that is not drawn adds NOTHING, also when its partial sum is NaN
+          const double wr = w[(uint64_t)(ks + u) * w_stride + r];
+          acc[r] = wr != 0.0 ? __builtin_fma(wr, v[u], acc[r]) : acc[r];
+        }
     }
     for (; ks < n_ks; ks++) {
       const double v = p[(uint64_t)ks * plane];
 #pragma unroll
-      for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)ks * w_stride + r], v, acc[r]);
+      for (int r = 0; r < RB; r++) {
+        const double wr = w[(uint64_t)ks * w_stride + r];
+        acc[r] = wr != 0.0 ? __builtin_fma(wr, v, acc[r]) : acc[r];
+      }
     }
   }
   const uint64_t idx = ngd_pair_idx(n_ind, i, j);

@@ -419,13 +419,40 @@ def test_all_zero_site_vectors_count_and_contribute_nothing():
         s, c = gpu_pairs(p, "mfma", pairwise_del=pd)
         so, co = O.all_pairs(p, pairwise_del=pd)
         assert np.array_equal(c, co) and rel_err(s, so) < RTOL
-        for k in ("em_fast", "em_faithful"):
+        for k in EM_KERNELS:
             s, c = gpu_pairs(p, k, pairwise_del=pd, indep_geno=False)
             so, co = O.all_pairs(p, pairwise_del=pd, indep_geno=False)
             assert np.array_equal(c, co)
             assert np.array_equal(np.isnan(s), np.isnan(so))
             ok = ~np.isnan(so)
             assert rel_err(s[ok], so[ok]) < RTOL
+
+
+@pytest.mark.parametrize("kernel", EM_KERNELS)
+@pytest.mark.parametrize("partials", [0, 1])
+def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel, partials):
+    """EM path, no --pairwise_del: a (0,0,0) site makes its pairs' sums NaN (0/0 in normalize(), as on the CPU) -- in
+    the full-data matrix and in exactly those bootstrap replicates that draw the site's block; a replicate that does
+    not draw it must come out finite whichever plan forms it (a weight of zero adds nothing: not 0 x NaN)."""
+    n_ind, n_sites, B = 7, 96, 8
+    p = O.synth_indmajor(4, n_ind, n_sites)
+    p[3, 20] = 0.0  # block 2
+    t = N().Taus(11)
+    maps = np.stack([t.block_map(n_sites // B) for _ in range(12)])
+    assert any(2 in m for m in maps) and any(2 not in m for m in maps)
+    with N().Engine(n_ind, n_sites, indep_geno=False, kernel=kernel) as e:
+        e.set_option("boot_partials", partials)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, B)
+        S1 = np.stack([e.run(m, B)[0] for m in maps])
+    for r, m in enumerate([None] + list(maps)):
+        so, co = O.all_pairs(p, indep_geno=False, site_src=None if m is None else O.boot_site_src(m, B), n_sites=n_sites)
+        assert np.array_equal(Cn[r], co)
+        assert np.array_equal(np.isnan(S[r]), np.isnan(so)), (r, m)
+        ok = ~np.isnan(so)
+        assert rel_err(S[r][ok], so[ok]) < RTOL
+        if m is not None:
+            assert np.array_equal(np.isnan(S1[r - 1]), np.isnan(so))
 
 
 # ---- site sharding: engines hold contiguous ranges of sites, (sum, cnt) are added -----------------------

@@ -4,7 +4,7 @@ GSL rng/test.c: `rng_test (gsl_rng_taus, 1, 10000, 2733957125UL);`
 (seed 1, the 10000th output).  GSL is a third-party dependency of the
 reference (README.md:20, "gsl v1.15") that is absent from /root/reference and
 from this image; the algorithm is restated in oracle/ngsdist_oracle.c and in
-the product's host code (ngsdist_amd/csrc/host/taus.hpp).
+the product's host code (ngsdist_amd/csrc/host_util.cpp, checked through the ABI in tests/test_abi.py).
 """
 import numpy as np
 

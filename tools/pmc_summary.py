@@ -94,7 +94,12 @@ for k in sorted({k for (k, _) in agg}):
     print()
 
 if traffic:
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src_sha = {}
+    for f in sorted(glob.glob(os.path.join(root, "ngsdist_amd", "csrc", "accum_*.hip"))):
+        src_sha[os.path.basename(f)] = hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
     with open(os.path.join(out, "traffic.json"), "w") as fh:
-        json.dump({"source": os.path.basename(out), "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+        json.dump({"source": os.path.basename(out), "kernel_source_sha16": src_sha, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                    "FETCH_SIZE x 1024 x 2 (gfx950: reads of a wide coalesced stream are counted at half), WRITE_SIZE x 1024",
                    "per_launch": traffic}, fh, indent=1)
