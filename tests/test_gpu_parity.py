@@ -291,11 +291,11 @@ def test_synth_fill_matches_oracle_generator():
         assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "stream", "em_fast"])
+@pytest.mark.parametrize("kernel", ["mfma", "stream", "em_fast", "em_table"])
 def test_shards_partition_the_pairs(kernel):
     n_ind, n_sites, world = 300, 256, 3
     p = O.synth_indmajor(8, n_ind, n_sites)
-    indep = kernel != "em_fast"
+    indep = kernel in INDEP_KERNELS
     tot_s = np.zeros(N().n_pairs(n_ind))
     tot_c = np.zeros(N().n_pairs(n_ind), dtype=np.uint64)
     owned = np.zeros(N().n_pairs(n_ind), dtype=np.int32)
@@ -345,7 +345,7 @@ def _raw_gl(n_ind, n_sites, seed):
     return raw
 
 
-@pytest.mark.parametrize("kernel,indep", [("mfma", True), ("stream", True), ("em_fast", False)])
+@pytest.mark.parametrize("kernel,indep", [("mfma", True), ("stream", True), ("em_fast", False), ("em_table", False)])
 def test_device_prep_matches_host_prep(kernel, indep):
     n_ind, n_sites = 50, 3001
     raw = _raw_gl(n_ind, n_sites, 5)
@@ -403,9 +403,10 @@ def test_tile_boundaries_and_many_tiles(n_ind, n_sites):
     s, c = gpu_pairs(p, "mfma", pairwise_del=True)
     assert np.array_equal(c, co) and rel_err(s, so) < RTOL
     if n_ind <= 400:
-        s, c = gpu_pairs(p, "em_fast", pairwise_del=True, indep_geno=False)
         so, co = O.all_pairs(p, pairwise_del=True, indep_geno=False, n_threads=8)
-        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        for k in ("em_fast", "em_table"):
+            s, c = gpu_pairs(p, k, pairwise_del=True, indep_geno=False)
+            assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
 def test_all_zero_site_vectors_count_and_contribute_nothing():
@@ -456,10 +457,10 @@ def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel,
 
 
 # ---- site sharding: engines hold contiguous ranges of sites, (sum, cnt) are added -----------------------
-@pytest.mark.parametrize("kernel", ["mfma", "em_fast", "stream"])
+@pytest.mark.parametrize("kernel", ["mfma", "em_fast", "em_table", "stream"])
 def test_site_shards_add_up(kernel):
     n_ind, n_sites, B, world = 70, 1200, 20, 3
-    indep = kernel != "em_fast"
+    indep = kernel in INDEP_KERNELS
     p = O.synth_indmajor(23, n_ind, n_sites, miss_frac=0.1)
     cuts = [0, 400, 820, 1200]  # whole blocks of 20 sites per shard
     engines = []
