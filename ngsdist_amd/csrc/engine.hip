@@ -739,9 +739,11 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
       // what this call costs without the partials: a list-driven pass per replicate (MFMA, ~3/4 of a pass)
       // or a batch pass per 16 replicates (EM); rates are the measured ones of DESIGN.md section 6
       const double ps = (double)e->n_owned_pairs * (double)n_eff;
-      const double pass_ms = mfma ? ps / 1.05e10 : e->kernel == NGD_KERNEL_EM_TABLE ? ps / 3e8
-                             : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
-      const double alt_ms = mfma ? 0.75 * pass_ms * n_rep : 1.1 * pass_ms * ((n_rep + 15) / 16);
+      const bool table = e->kernel == NGD_KERNEL_EM_TABLE;
+      const double pass_ms = mfma ? ps / 1.05e10 : table ? ps / 1.9e8 : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
+      const double alt_ms = mfma ? 0.75 * pass_ms * n_rep
+                            : table ? std::min(0.65 * pass_ms * n_rep, 2.9 * pass_ms * ((n_rep + 15) / 16))
+                                    : 1.1 * pass_ms * ((n_rep + 15) / 16);
       if (e->rent_B != block_size || e->rent_blocks != n_blocks) {
         e->rent_B = block_size; e->rent_blocks = n_blocks; e->rent_ms = 0;
       }
@@ -840,7 +842,17 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   const uint64_t n_pairs = ngd_n_pairs(g.n_ind), plane = (uint64_t)g.n_pad * g.n_pad;
   const uint64_t n_eff = n_blocks * block_size;
   const uint32_t n_mat = n_rep + (lead_full ? 1u : 0u);
-  const bool fast = e->kernel == NGD_KERNEL_EM_FAST;
+  const bool fast = e->kernel != NGD_KERNEL_EM_FAITHFUL;
+  // slices of the per-pair batch kernel: the engine's own when that is its kernel, else (table-driven engine) what
+  // ngd_create() would have picked for it
+  uint32_t b_ks = e->n_ks;
+  uint64_t b_per = e->per_slice;
+  if (e->kernel == NGD_KERNEL_EM_TABLE) {
+    uint64_t ks = e->n_tiles16 ? (4096 + e->n_tiles16 - 1) / e->n_tiles16 : 1;
+    ks = std::max<uint64_t>(1, std::min(ks, std::max<uint64_t>(1, g.n_sites / 256)));
+    b_ks = (uint32_t)ks;
+    b_per = (g.n_sites + ks - 1) / ks;
+  }
   HIPCHK(hipMemsetAsync(d_sum, 0, (uint64_t)n_mat * n_pairs * sizeof(double), e->st));
   HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_mat * n_pairs * sizeof(unsigned long long), e->st));
   e->boot_B = 0;  // the partial-sum slab is re-used as this pass's scratch
@@ -850,7 +862,7 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
     const bool lead = lead_full && c0 == 0;
     const uint32_t q0 = c0 - ((lead_full && c0 > 0) ? 1u : 0u);  // first replicate of the chunk
     const uint32_t nq = nr - (lead ? 1u : 0u);                     // replicates in the chunk
-    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (uint64_t)e->n_ks * rb * plane);
+    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (uint64_t)b_ks * rb * plane);
     if (rc) return rc;
     rc = ensure_cap(e, &e->d_W, &e->cap_W, g.n_sites * (uint64_t)rb);
     if (rc) return rc;
@@ -862,11 +874,11 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
                              e->d_W);
     HIPCHK(hipEventRecord(e->ev[1], e->st));
     ngd_launch_accum_em_batch(e->st, g, e->PA, e->d_W, rb, lead ? g.n_sites : n_eff, e->sc, e->cfg.pairwise_del, fast,
-                              e->d_tiles16, e->n_tiles16, e->n_ks, e->per_slice, e->slab_boot);
+                              e->d_tiles16, e->n_tiles16, b_ks, b_per, e->slab_boot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[2], e->st));
     for (uint32_t r = 0; r < nr; r++)
-      ngd_launch_reduce(e->st, g, e->slab_boot + (uint64_t)r * plane, e->n_ks, (uint32_t)rb, e->d_tiles, e->n_tiles,
+      ngd_launch_reduce(e->st, g, e->slab_boot + (uint64_t)r * plane, b_ks, (uint32_t)rb, e->d_tiles, e->n_tiles,
                         d_sum + (uint64_t)(c0 + r) * n_pairs);
     HIPCHK(hipEventRecord(e->ev[3], e->st));
     for (uint32_t r = 0; r < nr; r++) {
@@ -968,11 +980,16 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
     if (rc) return rc;
     if (feasible) return lead ? pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, true) : NGD_OK;
   }
-  // 2. EM kernels: many matrices per accumulation pass.  The faithful form keeps matrix 0 on the plain pass,
-  //    whose accumulation is the reference's term by term.
-  const bool em = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
-  if (em && n_rep + lead >= 2 && e->opt_em_batch) {
-    const bool fold = lead && e->kernel == NGD_KERNEL_EM_FAST;
+  // 2. EM kernels: many matrices per accumulation pass (the per-pair kernels' batch form: the EM of a (pair, site) is
+  //    computed once and added to up to 16 accumulators).  The faithful form keeps matrix 0 on the plain pass, whose
+  //    accumulation is the reference's term by term.  The table-driven kernel has no batch form (16 x 8 accumulators do
+  //    not fit its registers); its weighted pass walks only the sites a replicate drew (0.63 of a pass), which is
+  //    cheaper than the per-pair batch pass (2.5 of its own plain passes) up to two replicates -- beyond that the
+  //    table engine borrows the per-pair batch kernel, and those replicates agree with ngd_run()'s to rounding only.
+  const bool em_pair = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
+  const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && n_rep >= 3;
+  if ((em_pair || em_borrow) && n_rep + lead >= 2 && e->opt_em_batch) {
+    const bool fold = lead && e->kernel != NGD_KERNEL_EM_FAITHFUL;
     if (lead && !fold) {
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
       if (rc) return rc;

@@ -256,10 +256,16 @@ def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
         assert S.shape == (n_rep + 1, e.n_pairs)
         s0, c0 = e.run()
         assert np.array_equal(Cn[0], c0) and rel_err(S[0], s0) < 1e-12
+        # the table-driven EM engine borrows the per-pair kernel's batch pass from three replicates on (no partials):
+        # those agree with its own weighted pass to rounding, everything else bit for bit
+        borrowed = kernel == "em_table" and not partials and n_rep >= 3
         for r in range(n_rep):
             s1, c1 = e.run(maps[r], block_size)
             assert np.array_equal(Cn[r + 1], c1)
-            assert np.array_equal(S[r + 1], s1)
+            if borrowed:
+                assert rel_err(S[r + 1], s1) < 1e-12
+            else:
+                assert np.array_equal(S[r + 1], s1)
         if n_rep:  # and a batch without the leading matrix
             S2, C2 = e.run_batch(maps, block_size)
             assert np.array_equal(S2, S[1:]) and np.array_equal(C2, Cn[1:])
