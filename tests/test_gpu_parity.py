@@ -124,6 +124,29 @@ def test_em(kernel, n_ind, n_sites, miss):
         assert rel_err(s, so) < RTOL
 
 
+@pytest.mark.parametrize("kernel", EM_KERNELS)
+def test_em_on_degenerate_likelihoods(kernel):
+    """EM path on the likelihood vectors real inputs are full of: certain genotypes (1,0,0), exact ties (.5,.5,0),
+    missing data (1/3,1/3,1/3), nearly certain ones (1-2e-12, 1e-12, 1e-12) and tiny-but-nonzero entries -- every
+    combination of them as a pair, at a site each, against the oracle (their EM stops at step 1 or needs all 50)."""
+    pats = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (.5, .5, 0), (0, .5, .5), (.5, 0, .5), (1 / 3, 1 / 3, 1 / 3),
+            (1 - 2e-12, 1e-12, 1e-12), (1e-12, 1 - 2e-12, 1e-12), (0.999, 0.001, 1e-300), (0.34, 0.33, 0.33),
+            (0.3334, 0.3333, 0.3333), (0.6, 0.4, 1e-200), (0.25, 0.5, 0.25)]
+    n = len(pats)
+    rng = np.random.default_rng(0)
+    n_ind, n_sites = 9, 4 * n * n
+    p = np.zeros((n_ind, n_sites, 3))
+    for s in range(n_sites):  # individuals 0 and 1 run through every ordered pair of patterns, the others are random picks
+        p[0, s], p[1, s] = pats[(s // n) % n], pats[s % n]
+        for i in range(2, n_ind):
+            p[i, s] = pats[int(rng.integers(0, n))]
+    for pd in (False, True):
+        s, c = gpu_pairs(p, kernel, pairwise_del=pd, indep_geno=False)
+        so, co = O.all_pairs(p, pairwise_del=pd, indep_geno=False, n_threads=8)
+        assert np.array_equal(c, co)
+        assert np.isfinite(so).all() and rel_err(s, so) < RTOL
+
+
 @pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
 @pytest.mark.parametrize("block_size", [1, 7, 64])
 def test_bootstrap_replicates(kernel, block_size):
