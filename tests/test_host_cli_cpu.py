@@ -60,3 +60,20 @@ def test_single_dash_long_options_are_accepted(tmp_path):
     # getopt_long_only: "-n_ind 3" works like "--n_ind 3" (parse_args.cpp:83)
     r = run("-geno", "x", "-n_ind", "3", "-verbose", "0")
     assert "number of sites (--n_sites) missing!" in r.stderr
+
+
+def test_gpu_options_are_checked_before_any_gpu_work(tmp_path):
+    r = run("--geno", "x", "--n_ind", "3", "--n_sites", "4", "--out", "o", "--n_gpus", "0", "--verbose", "0")
+    assert r.returncode == 255 and "number of GPUs cannot be less than 1!" in r.stderr
+    r = run("--geno", "x", "--n_ind", "3", "--n_sites", "4", "--out", "o", "--kernel", "no_such_kernel", "--verbose", "0")
+    assert r.returncode == 255
+
+
+def test_without_a_device_the_host_says_so_instead_of_falling_back(tmp_path):
+    import ngsdist_amd as N
+    if N.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = run("--geno", os.path.join(SP, "t_gl.bin"), "--probs", "--n_ind", "6", "--n_sites", "200", "--out",
+            str(tmp_path / "o"), "--verbose", "0", "--n_gpus", "2", "--same_device")
+    assert r.returncode == 255 and "no HIP device found (this program has no CPU path)" in r.stderr
+    assert not os.path.exists(str(tmp_path / "o")) or os.path.getsize(str(tmp_path / "o")) == 0
