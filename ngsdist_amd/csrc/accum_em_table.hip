@@ -78,7 +78,7 @@ __device__ __forceinline__ void scan4(uint64_t &m, uint32_t &n, double r0, doubl
       "s_mov_b64 exec, %[keep]"
       : [m] "+s"(m), [n] "+v"(n), [keep] "=&s"(keep)
       : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3)
-      : "vcc");
+      : "vcc", "scc");  // v_cmpx writes VCC next to EXEC on gfx9; s_and_b64 writes SCC
 }
 
 __device__ __forceinline__ double rcp_nr(double a) {
