@@ -877,9 +877,12 @@ int main(int argc, char **argv) {
     std::vector<double> &tot_sum = dev_sum[0];
     std::vector<uint64_t> &tot_cnt = dev_cnt[0];
     if (tot_sum.empty()) { tot_sum.assign(n_mat * n_comb, 0.0); tot_cnt.assign(n_mat * n_comb, 0); }
-    for (uint64_t d = 1; d < G; d++)
-      if (!dev_sum[d].empty())
-        for (uint64_t k = 0; k < n_mat * n_comb; k++) { tot_sum[k] += dev_sum[d][k]; tot_cnt[k] += dev_cnt[d][k]; }
+    // devices in ascending order for every cell, cells on --n_threads threads
+    parallel_for(p.n_threads, n_mat * n_comb, 1u << 16, [&](uint64_t lo, uint64_t hi) {
+      for (uint64_t d = 1; d < G; d++)
+        if (!dev_sum[d].empty())
+          for (uint64_t k = lo; k < hi; k++) { tot_sum[k] += dev_sum[d][k]; tot_cnt[k] += dev_cnt[d][k]; }
+    });
     for (uint64_t rep = 0; rep < n_mat; rep++)
       emit(rep, &tot_sum[rep * n_comb], &tot_cnt[rep * n_comb],
            rep && !maps_kept.empty() ? &maps_kept[(rep - 1) * n_blocks] : nullptr, n_blocks);
