@@ -124,6 +124,19 @@ def test_em(kernel, n_ind, n_sites, miss):
         assert rel_err(s, so) < RTOL
 
 
+@pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
+def test_score_matrix_need_not_be_symmetric(kernel):
+    """the ABI takes any 3 x 3 score (params.score, ngsDist.hpp:20): the first individual of a pair indexes its rows
+    (ngsDist.cpp:351-353) -- checked with a score that is neither symmetric nor zero on the diagonal"""
+    sc = np.array([0.1, 0.7, 1.3, 0.2, 0.05, 0.9, 1.1, 0.4, 0.3])
+    p = O.synth_indmajor(77, 70, 300, miss_frac=0.1)
+    indep = kernel in INDEP_KERNELS
+    for pd in (False, True):
+        s, c = gpu_pairs(p, kernel, pairwise_del=pd, indep_geno=indep, score=sc)
+        so, co = O.all_pairs(p, score=sc, pairwise_del=pd, indep_geno=indep, n_threads=8)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
 @pytest.mark.parametrize("kernel", EM_KERNELS)
 def test_em_on_degenerate_likelihoods(kernel):
     """EM path on the likelihood vectors real inputs are full of: certain genotypes (1,0,0), exact ties (.5,.5,0),
