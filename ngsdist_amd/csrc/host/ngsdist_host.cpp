@@ -510,18 +510,44 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
     const uint64_t need = n_ind * n_geno;
     std::vector<char> line(std::max<size_t>(kLineBuf, need * 32 + 4096));
     const uint64_t group = std::max<uint64_t>(1, std::min<uint64_t>(chunk, 1024));
-    std::vector<std::string> lines;
+    std::vector<std::string> lines, ahead;
     std::vector<std::vector<double>> toks(group);
     std::vector<int64_t> slot(group);  // site slot within the group, or -1
     uint64_t s = 0;
-    while (s < n_sites) {
-      lines.clear();
-      // a little read-ahead for header lines -- in the last part only: lines past a part belong to the next one
-      while (lines.size() < group && lines.size() < n_sites - s + (last_part ? 64 : 0)) {
-        if (gzgets(fh, line.data(), (int)line.size()) == nullptr) { eof = true; break; }
+    // up to `max_lines` lines of the stream (decompression + line splitting: the sequential part of a text load)
+    // (*hit_end: the stream ended before max_lines were read)
+    auto read_lines_into = [&](std::vector<std::string> &out, uint64_t max_lines, bool *hit_end) {
+      out.clear();
+      *hit_end = false;
+      while (out.size() < max_lines) {
+        if (gzgets(fh, line.data(), (int)line.size()) == nullptr) { *hit_end = true; break; }
         chomp(line.data());
-        lines.emplace_back(line.data());
+        out.emplace_back(line.data());
       }
+    };
+    bool have_ahead = false, end_ahead = false;
+    while (s < n_sites) {
+      if (have_ahead) {
+        lines.swap(ahead);
+        eof = end_ahead;
+        have_ahead = false;
+      } else {
+        // a little read-ahead for header lines -- in the last part only: lines past a part belong to the next one
+        read_lines_into(lines, std::min<uint64_t>(group, n_sites - s + (last_part ? 64 : 0)), &eof);
+      }
+      // The NEXT group is decompressed by a reader thread while this one is tokenised, parsed and uploaded.  It may
+      // take only lines that belong to this part whatever this group turns out to hold: at least n_sites - s - (lines
+      // of this group) sites are still to come after it.
+      std::thread reader;
+      {
+        const uint64_t sure = n_sites - s > lines.size() ? n_sites - s - lines.size() : 0;
+        const uint64_t next_max = std::min<uint64_t>(group, sure + (last_part && sure ? 64 : 0));
+        if (next_max && !eof && !lines.empty()) {
+          reader = std::thread([&, next_max]() { read_lines_into(ahead, next_max, &end_ahead); });
+          have_ahead = true;
+        }
+      }
+      struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
       if (lines.empty()) {
         if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
         die("read_geno", "cannot read GZip GENO file. Check GENO file and number of sites!");
