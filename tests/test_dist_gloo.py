@@ -231,3 +231,18 @@ def test_two_rank_job_reduce_scatter_finish_all_gather():
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert all(ok for _, ok, _ in res)          # every rank ends up with every finished cell
     assert sum(n for _, _, n in res) == 5 * 78  # the shares partition the job's cells
+
+
+def test_share_of_partitions_any_job_into_equal_buffers():
+    os.environ.setdefault("NGD_NO_TORCH", "1")
+    from ngsdist_amd.dist import share_of
+    for total in (1, 7, 499500, 65 * 124750, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            chunks = [share_of(total, r, world) for r in range(world)]
+            assert len({c for c, _, _ in chunks}) == 1 and chunks[0][0] * world >= total  # equal buffers that cover the job
+            covered = 0
+            for r, (chunk, lo, hi) in enumerate(chunks):
+                assert lo == min(total, r * chunk) and lo <= hi <= total and hi - lo <= chunk
+                assert lo == covered or lo == total
+                covered = hi
+            assert covered == total
