@@ -390,11 +390,17 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       const uint32_t cus_per_xcd = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8
                                        ? (uint32_t)prop.multiProcessorCount / 8 : 32;
       const double slots = (double)cus_per_xcd * (e->exact_shapes ? 12 : 3);
+      // ... plus what the slice count costs afterwards: the slab reduction reads one plane per slice ([measured] 0.8 us
+      // per slice at n_ind = 1000, i.e. ~5 TB/s), against an accumulation pass at ~0.8 of the FP64 peak.  It decides
+      // between slice counts that fill their rounds equally well: a 1/8 site shard of cfg 3 takes 112 slices instead
+      // of 248 (6.36 instead of 6.54 ms per matrix, the accumulation itself is flat from 88 to 500 slices).
+      const double accum_s = 6.0 * (double)e->n_owned_pairs * (double)g.n_sites / (0.8 * 78.6e12);
+      const double reduce_s_per_slice = 8.0 * (double)e->n_owned_pairs / 5e12;
       double best = 1e30;
       uint64_t best_ks = ks;
-      for (uint64_t c = std::max<uint64_t>(8, ks / 2 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
+      for (uint64_t c = std::max<uint64_t>(8, ks / 3 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
         const double rounds = (double)wg_per_slice * (double)(c / 8) / slots;
-        const double waste = std::ceil(rounds - 1e-9) / rounds + 1e-4 * std::fabs((double)c - (double)ks) / (double)ks;
+        const double waste = std::ceil(rounds - 1e-9) / rounds + (double)c * reduce_s_per_slice / std::max(accum_s, 1e-9);
         if (waste < best) { best = waste; best_ks = c; }
       }
       ks = best_ks;
