@@ -119,15 +119,9 @@ __device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, c
     if (ROW) {
       double q = (E * (A[k] * A[k])) * (r[k + 1] * r[k - 1]);
       if (force) q = __builtin_inf();
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 3  // timing experiment: tables computed, not stored
-      asm volatile("" ::"v"(q), "v"(f[0]), "v"(f[1]), "v"(f[2]));
-      if (tfirst < 0)
-#endif
-      {
       L.Qr[lane * RS + tt] = q;
 #pragma unroll
       for (int x = 0; x < 3; x++) L.Fr[x][lane * RS + tt] = f[x];
-      }
     } else {
       double rr = (A[k + 1] * A[k - 1]) * (r[k] * r[k]);
       if (force) rr = 0.0;
@@ -135,20 +129,14 @@ __device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, c
 #pragma unroll
       for (int x = 0; x < 3; x++)
         gg[x] = __builtin_fma(sc.v[3 * x + 2], f[2], __builtin_fma(sc.v[3 * x + 1], f[1], sc.v[3 * x] * f[0]));
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 3
-      asm volatile("" ::"v"(rr), "v"(gg[0]), "v"(gg[1]), "v"(gg[2]));
-      if (tfirst < 0)
-#endif
-      {
       L.Rc[tt * TS + lane] = rr;
 #pragma unroll
       for (int x = 0; x < 3; x++) L.Gc[x][tt * TS + lane] = gg[x];
-      }
     }
   }
 }
 
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5  // diagnostic build: where a wavefront's cycles go (tools/em_stamps.py)
+#if defined(NGD_EMT_STAMPS)  // diagnostic build: where a wavefront's cycles go (tools/em_stamps.py)
 #define EMT_STAMP(slot)                                                              \
   do {                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                               \
@@ -206,10 +194,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   const double *pb = PA + (uint64_t)(bind >> 4) * 64 + (bind & 15);
   const uint64_t kstride = (uint64_t)n_ig * 64;  // doubles between consecutive k-groups
   auto load_site = [&](uint64_t s, double *g) {
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 4  // timing experiment: no global loads
-    g[0] = 0.5 + 0.001 * (double)((s + lane) & 63); g[1] = 0.3; g[2] = 0.2 - 0.001 * (double)((s + lane) & 63);
-    return;
-#endif
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const uint64_t k = 3 * s + c;
@@ -222,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   uint32_t round = 0;  // table rounds so far (all sites): parity selects the flag word
   uint32_t sites_done = 0;
 
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+#if defined(NGD_EMT_STAMPS)
   double stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
@@ -231,7 +215,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     double wgt = 1.0;
     EMT_STAMP(0);  // loop overhead, end-of-site
     double g[3] = {gn[0], gn[1], gn[2]};
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+#if defined(NGD_EMT_STAMPS)
     asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]));  // the wait for the loads happens here
     EMT_STAMP(1);  // waiting for this site's likelihoods
 #endif
@@ -265,9 +249,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     EMT_STAMP(2);  // per-site set-up (powers)
     // (every pair has stopped by step MAX_ITER, where the tables force it: the bound only restates that)
     for (int t0 = 0; t0 < MAX_ITER; t0 += CH, round++) {  // steps t0+1 .. t0+CH
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 1  // timing experiment: tables built for the slice's first site only
-      if (s == s0)
-#endif
       {
         const int tfirst = t0 + (int)seg * SEG;  // this wavefront's steps are tfirst+1 .. tfirst+SEG
         if (is_row) build_round<CH, SEG, true>(L, v, g, sc, lane, seg, tfirst, miss);
@@ -281,12 +262,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       // the other parity's word: every wavefront has read it (it is behind that read), it is next written after the
       // next round's first barrier
       if (tid == 0) L.more[(round & 1) ^ 1] = 0;
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 2  // timing experiment: no scan, two rounds per site
-      if (t0 >= CH) todo = 0;
-      if (false) {
-#else
       if (__builtin_amdgcn_ballot_w64(todo != 0)) {
-#endif
         double R2[CH];
 #pragma unroll
         for (int tt = 0; tt < CH; tt++) R2[tt] = lds_b64(&L.Rc[tt * TS + lane]);
@@ -340,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     atomicAdd(&counters[0], (unsigned long long)sites_done);
     atomicAdd(&counters[1], (unsigned long long)round);
   }
-#if defined(NGD_EMT_ABLATE) && NGD_EMT_ABLATE == 5
+#if defined(NGD_EMT_STAMPS)
 #pragma unroll
   for (int r = 0; r < RPW && r < 8; r++) acc[r] = stamp_sum[r];
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/em_stamps.py [n_sites] [shape] -- reads the cycle stamps of a -DNGD_EMT_ABLATE=5 build of the table-driven
+"""tools/em_stamps.py [n_sites] [shape] -- reads the cycle stamps of a -DNGD_EMT_STAMPS build (tools/em_stamps.sh) of the table-driven
 EM kernel (diagnostic build: the 'sums' it returns are per-wavefront cycle totals per phase, not distances)."""
 import os
 import sys
