@@ -209,8 +209,13 @@ __global__ __launch_bounds__(256) void k_accum_em_batch(const double *__restrict
       if (PDEL && (ngd_miss(g1[0], g1[1], g1[2]) || ngd_miss(g2[0], g2[1], g2[2]))) continue;
       // the site's score-weighted sum, exactly as the one-replicate kernel forms it (0 + c * 1 == c)
       const double c = FAST ? site_fast(g1, g2, sc, 0.0, 1.0) : site_faithful(g1, g2, sc, 0.0, 1.0, true);
+      if (__builtin_fabs(c) <= 1.7976931348623157e308) {
 #pragma unroll
-      for (int r = 0; r < RB; r++) acc[r] = w[r] != 0.0 ? acc[r] + c * w[r] : acc[r];  // not drawn: adds nothing, NaN included
+        for (int r = 0; r < RB; r++) acc[r] = acc[r] + c * w[r];
+      } else {  // NaN (an all-zero site): only the replicates that draw the site take it -- 0 x NaN must add nothing
+#pragma unroll
+        for (int r = 0; r < RB; r++) acc[r] = w[r] != 0.0 ? acc[r] + c * w[r] : acc[r];
+      }
     }
   }
 #pragma unroll

@@ -9,6 +9,12 @@
 
 namespace {
 
+// A block that is NOT drawn (weight 0) must add nothing even when its partial sum is NaN (the EM of an all-zero site,
+// 0/0 as on the CPU): 0 x NaN would poison replicates that never visit the site.  A select per (slice, replicate)
+// makes this memory-bound kernel VALU-bound ([measured] cfg 5: 0.43 -> 1.31 ms; a branch per slice 0.89 ms), so the main
+// loop only NOTES a non-finite partial and a pair that met one is summed again with the undrawn blocks left out.
+__device__ __forceinline__ bool ngd_finite(double v) { return __builtin_fabs(v) <= 1.7976931348623157e308; }
+
 // grid = owned 128-tiles x 128 rows; 128 threads = columns.  Eight interleaved partial sums (slice
 // ks goes to partial ks % 8) keep eight loads in flight per thread; they are combined in a fixed tree,
 // so the result is a fixed function of the slabs (deterministic), just not the left-to-right sum.
@@ -63,24 +69,34 @@ __global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ sl
   } else {
     constexpr int U = 4;  // slices in flight per thread
     uint32_t ks = 0;
+    bool bad = false;  // a non-finite partial among this pair's slices
     for (; ks + U <= n_ks; ks += U) {
       double v[U];
 #pragma unroll
       for (int u = 0; u < U; u++) v[u] = p[(uint64_t)(ks + u) * plane];
 #pragma unroll
+      for (int u = 0; u < U; u++) bad |= !ngd_finite(v[u]);
+#pragma unroll
       for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int r = 0; r < RB; r++) {  // a block that is not drawn adds NOTHING, also when its partial sum is NaN
-          const double wr = w[(uint64_t)(ks + u) * w_stride + r];
-          acc[r] = wr != 0.0 ? __builtin_fma(wr, v[u], acc[r]) : acc[r];
-        }
+        for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)(ks + u) * w_stride + r], v[u], acc[r]);
     }
     for (; ks < n_ks; ks++) {
       const double v = p[(uint64_t)ks * plane];
+      bad |= !ngd_finite(v);
 #pragma unroll
-      for (int r = 0; r < RB; r++) {
-        const double wr = w[(uint64_t)ks * w_stride + r];
-        acc[r] = wr != 0.0 ? __builtin_fma(wr, v, acc[r]) : acc[r];
+      for (int r = 0; r < RB; r++) acc[r] = __builtin_fma(w[(uint64_t)ks * w_stride + r], v, acc[r]);
+    }
+    if (__builtin_expect(bad, 0)) {  // again, slices in the same order, blocks that are not drawn left out
+#pragma unroll
+      for (int r = 0; r < RB; r++) acc[r] = 0;
+      for (ks = 0; ks < n_ks; ks++) {
+        const double v = p[(uint64_t)ks * plane];
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+          const double wr = w[(uint64_t)ks * w_stride + r];
+          if (wr != 0.0) acc[r] = __builtin_fma(wr, v, acc[r]);
+        }
       }
     }
   }
