@@ -168,6 +168,16 @@ def test_cfg5_whole_job_in_one_batch_with_pairwise_deletion():
             k += 1
 
 
+def test_many_individuals_em_path_against_the_oracle():
+    """n_ind = 2000 on the EM path (32 x 32 tiles of 64, 2.0e6 pairs), few sites: every pair against the oracle."""
+    n_ind, n_sites = 2000, 48
+    p = O.synth_indmajor(10, n_ind, n_sites, miss_frac=0.1)
+    so, co = O.all_pairs(p, pairwise_del=True, indep_geno=False, n_threads=16)
+    with N().Engine(n_ind, n_sites, kernel="em_table", pairwise_del=True, indep_geno=False) as e:
+        s, c = e.synth_fill(10, 0.1).run()
+    assert np.array_equal(c, co) and rel(s, so) < RTOL
+
+
 def test_many_individuals_against_the_oracle():
     """n_ind = 3000 (24 x 24 pair tiles, 4.5e6 pairs), few sites: every pair against the oracle."""
     n_ind, n_sites = 3000, 200
