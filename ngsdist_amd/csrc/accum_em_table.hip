@@ -81,6 +81,42 @@ __device__ __forceinline__ void scan4(uint64_t &m, uint32_t &n, double r0, doubl
       : "vcc", "scc");  // v_cmpx writes VCC next to EXEC on gfx9; s_and_b64 writes SCC
 }
 
+// Eight steps in one block: EXEC is saved and restored once, and the second four steps are jumped over when every lane
+// has stopped -- per step the same two VALU instructions as scan4, but 5 scalar instructions per 8 steps instead of 14
+// (scalar instructions and taken branches cost a wavefront issue slots like vector ones).
+__device__ __forceinline__ void scan8(uint64_t &m, uint32_t &n, double r0, double r1, double r2, double r3, double r4,
+                                      double r5, double r6, double r7, double q0, double q1, double q2, double q3,
+                                      double q4, double q5, double q6, double q7) {
+  uint64_t keep;
+  asm volatile(
+      "s_mov_b64 %[keep], exec\n\t"
+      "s_and_b64 exec, exec, %[m]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r0], %[q0]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r1], %[q1]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r2], %[q2]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r3], %[q3]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "s_cbranch_execz .Lngd_scan8_%=\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r4], %[q4]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r5], %[q5]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r6], %[q6]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, %[r7], %[q7]\n\t"
+      "v_add_u32_e32 %[n], 1, %[n]\n"
+      ".Lngd_scan8_%=:\n\t"
+      "s_mov_b64 %[m], exec\n\t"
+      "s_mov_b64 exec, %[keep]"
+      : [m] "+s"(m), [n] "+v"(n), [keep] "=&s"(keep)
+      : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [r3] "v"(r3), [r4] "v"(r4), [r5] "v"(r5), [r6] "v"(r6), [r7] "v"(r7),
+        [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [q4] "v"(q4), [q5] "v"(q5), [q6] "v"(q6), [q7] "v"(q7)
+      : "vcc", "scc");
+}
+
 __device__ __forceinline__ double rcp_nr(double a) {
   double y = __builtin_amdgcn_rcp(a);
   double e = __builtin_fma(-a, y, 1.0);
@@ -169,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   constexpr int RS = em_tables<CH>::RS;
   // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
   constexpr int GR = WPS >= 4 ? 1 : 4;
-  static_assert(RPW % GR == 0 && CH % 4 == 0, "shape");
+  static_assert(RPW % GR == 0 && CH % 4 == 0 && (CH % 8 == 0 || CH % 8 == 4), "shape");
   __shared__ em_tables<CH> L;
   const uint32_t tile = blockIdx.x % n_tiles;
   const uint32_t ks = blockIdx.x / n_tiles;
@@ -289,8 +325,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
             uint64_t m = __builtin_amdgcn_ballot_w64(mine);
             uint32_t n = 0;
 #pragma unroll
-            for (int b = 0; b < CH / 4; b++) {
+            for (int b = 0; b < CH / 8; b++) {
               if (b && m == 0) break;  // every lane has stopped
+              scan8(m, n, R2[8 * b], R2[8 * b + 1], R2[8 * b + 2], R2[8 * b + 3], R2[8 * b + 4], R2[8 * b + 5],
+                    R2[8 * b + 6], R2[8 * b + 7], Q[4 * b][0], Q[4 * b][1], Q[4 * b + 1][0], Q[4 * b + 1][1],
+                    Q[4 * b + 2][0], Q[4 * b + 2][1], Q[4 * b + 3][0], Q[4 * b + 3][1]);
+            }
+            if (CH % 8 && m != 0) {  // (12 steps per round: the last four)
+              constexpr int b = CH / 4 - 1;
               scan4(m, n, R2[4 * b], R2[4 * b + 1], R2[4 * b + 2], R2[4 * b + 3], Q[2 * b][0], Q[2 * b][1], Q[2 * b + 1][0],
                     Q[2 * b + 1][1]);
             }
