@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 }  // namespace
 
 // shape: 0 = 8 wavefronts x 8 rows, 16 steps per round, 4 waves per SIMD (default: [measured] 1000 x 2e4, ms per launch:
-//            51.1; shape 1: 61.2; 2: 54.0; 3: 67.1; k_accum_em<fast> 122.7);
+//            49.4; shape 1: 59.6; 2: 51.9; 3: 51.3; k_accum_em<fast> 122.7);
 //        1 = 4 wavefronts x 16 rows, 16 steps, 2 waves per SIMD (register-rich);  2 / 3 = the same two with 12 steps
 void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
