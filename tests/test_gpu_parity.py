@@ -114,7 +114,8 @@ def test_golden_em(kernel):
 
 @pytest.mark.parametrize("kernel", EM_KERNELS)
 @pytest.mark.parametrize("n_ind,n_sites,miss", [(2, 1, 0.0), (6, 200, 0.0), (33, 700, 0.1), (20, 5000, 0.0),
-                                                (65, 300, 0.05), (130, 257, 0.0)])
+                                                (65, 300, 0.05), (130, 257, 0.0), (64, 61, 0.0), (128, 33, 0.05),
+                                                (193, 24, 0.0)])
 def test_em(kernel, n_ind, n_sites, miss):
     p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=miss)
     for pd in (False, True):
@@ -352,13 +353,22 @@ def test_shards_partition_the_pairs(kernel):
     assert np.array_equal(tot_c, co) and rel_err(tot_s, so) < RTOL
 
 
-def test_deterministic_run_to_run():
-    p = O.synth_indmajor(2, 150, 4096)
-    with N().Engine(150, 4096, kernel="mfma") as e:
-        e.upload_ind_major(p).commit()
-        a = e.run()[0]
-        b = e.run()[0]
-    assert np.array_equal(a, b)
+@pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
+def test_deterministic_run_to_run(kernel):
+    """results must not depend on the run (slabs summed in fixed order, no floating-point atomics) --
+    the same engine twice, a second engine, and a bootstrap replicate formed twice: identical bits."""
+    n_ind, n_sites = 150, 4096
+    p = O.synth_indmajor(2, n_ind, n_sites, miss_frac=0.05)
+    indep = kernel in INDEP_KERNELS
+    bm = N().Taus(5).block_map(n_sites // 16)
+    out = []
+    for _ in range(2):
+        with N().Engine(n_ind, n_sites, indep_geno=indep, kernel=kernel, pairwise_del=True) as e:
+            e.upload_ind_major(p).commit()
+            out.append((e.run()[0], e.run()[0], e.run(bm, 16)[0], e.run(bm, 16)[0]))
+    a = out[0]
+    assert np.array_equal(a[0], a[1]) and np.array_equal(a[2], a[3])
+    assert np.array_equal(a[0], out[1][0]) and np.array_equal(a[2], out[1][2])
 
 
 def test_errors_are_codes_not_exits():
