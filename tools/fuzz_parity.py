@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""tools/fuzz_parity.py [first_seed] [n_cases] -- the sweep of tests/test_gpu_parity.py::test_random_shapes_flags_and_plans
+with other seeds and more cases: odd shapes, every kernel, random flags / block sizes / replicate counts / plans / launch
+geometry, ngd_run_job against the CPU oracle (test infrastructure; needs a GPU).  Prints the failing cases, exit 1 if any."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import ngsdist_amd as N
+from oracle import oracle as O
+
+RTOL = 1e-9
+first, n_cases = (int(sys.argv[1]) if len(sys.argv) > 1 else 1), (int(sys.argv[2]) if len(sys.argv) > 2 else 300)
+kernels = ["stream", "mfma", "em_faithful", "em_fast", "em_table"]
+bad = 0
+t_start = time.time()
+for case in range(first, first + n_cases):
+    rng = np.random.default_rng(case)
+    kernel = kernels[case % len(kernels)]
+    indep = kernel in ("stream", "mfma")
+    n_ind = int(rng.choice([2, 3, 5, 15, 16, 17, 31, 33, 63, 64, 65, 66, 127, 128, 129, 140, 193, 200]))
+    n_sites = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 127, 257, 700, 1000, 1025]))
+    if not indep and n_ind > 140:
+        n_sites = min(n_sites, 257)
+    pdel = bool(rng.integers(0, 2))
+    miss = float(rng.choice([0.0, 0.05, 0.3, 0.9]))
+    B = min(int(rng.choice([1, 2, 3, 4, 7, 8, 12, 50, 100])), n_sites)
+    n_rep = int(rng.choice([0, 1, 2, 3, 5, 17, 33]))
+    partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 3)) if kernel == "mfma" else 0,
+                variant=int(rng.integers(0, 4)) if kernel == "em_table" else 0)
+    score = O.score_matrix(bool(rng.integers(0, 2)))
+    model = int(rng.integers(0, 3))
+    p = O.synth_indmajor(1000 + case, n_ind, n_sites, miss_frac=miss)
+    if rng.integers(0, 4) == 0:  # called genotypes: one-hot vectors, sums must be bit-exact
+        g = np.argmax(p, axis=-1)
+        p = np.eye(3)[g]
+    n_eff = n_sites - n_sites % B
+    t = N.Taus(case)
+    maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
+    tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, geom)
+    try:
+        with N.Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
+            e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
+            e.upload_ind_major(p).commit()
+            S, Cn = e.run_job(maps, B)
+        for m in sorted({0, n_rep // 2, n_rep}):
+            src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
+            so, co = O.all_pairs(p, score=score, pairwise_del=pdel, indep_geno=indep, site_src=src,
+                                 n_sites=n_sites if m == 0 else n_eff, n_threads=8)
+            ok = np.array_equal(Cn[m], co)
+            fin = np.isfinite(so)
+            ok = ok and np.array_equal(np.isfinite(S[m]), fin)
+            if fin.any():
+                d = np.abs(S[m][fin] - so[fin])
+                ok = ok and bool(np.all(d <= RTOL * np.maximum(np.abs(so[fin]), 1e-300)))
+            with np.errstate(all="ignore"):
+                ok = ok and np.array_equal(N.finish(S[m], Cn[m], 0, model), O.finish(S[m], Cn[m], 0, model), equal_nan=True)
+            if not ok:
+                bad += 1
+                print("MISMATCH", tag, "matrix", m, flush=True)
+    except Exception as ex:  # noqa: BLE001
+        bad += 1
+        print("ERROR", tag, repr(ex), flush=True)
+    if (case - first) % 50 == 49:
+        print("... %d cases, %d bad, %.0f s" % (case - first + 1, bad, time.time() - t_start), flush=True)
+print("fuzz: %d cases from seed %d, %d bad" % (n_cases, first, bad))
+sys.exit(1 if bad else 0)
