@@ -636,6 +636,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   if (mult) {
     n_eff = n_blocks * block_size;
     while (n_planes < 32 && (mult_max >> n_planes)) n_planes++;
+    if (!n_planes) n_planes = 1;  // no block drawn (a site range of a larger job): one all-zero plane -- 0 planes means "unweighted"
     if (n_blocks > e->cap_blocks) {
       if (e->d_mult) { hipFree(e->d_mult); e->dev_bytes -= e->cap_blocks * 4; }
       e->d_mult = nullptr; e->cap_blocks = 0;
@@ -905,6 +906,7 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
       } else {
         uint32_t n_planes = 0;
         while (n_planes < 32 && (mult_max[q] >> n_planes)) n_planes++;
+        if (!n_planes) n_planes = 1;  // (as in pass_impl: a replicate that drew none of these blocks counts 0 sites)
         ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)(q - q0) * n_blocks, e->d_ws,
                            nullptr);
         ngd_launch_planes(e->st, e->d_ws, g.n_sites, g.n_words, n_planes, e->planes);

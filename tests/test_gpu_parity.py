@@ -508,6 +508,33 @@ def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel,
             assert np.array_equal(np.isnan(S1[r - 1]), np.isnan(so))
 
 
+@pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
+@pytest.mark.parametrize("partials", [0, 1])
+def test_replicate_that_draws_none_of_an_engines_blocks(kernel, partials):
+    """a site range of a larger job (site sharding, --n_gpus N, --max_device_bytes): some replicates draw NONE of this
+    engine's blocks.  Their partial (sum, cnt) must be exactly (0, 0) -- with --pairwise_del the per-pair count of a
+    replicate is a weighted popcount, and 'no weight planes' used to mean 'unweighted' (found by tools/fuzz_cli.py)."""
+    n_ind, n_sites, B = 9, 40, 10
+    p = O.synth_indmajor(31, n_ind, n_sites, miss_frac=0.2)
+    mult = np.array([[0, 0, 0, 0], [2, 0, 1, 0], [0, 0, 0, 0], [0, 3, 0, 1], [0, 0, 0, 0]], dtype=np.uint32)
+    indep = kernel in INDEP_KERNELS
+    for pd in (True, False):
+        with N().Engine(n_ind, n_sites, indep_geno=indep, kernel=kernel, pairwise_del=pd) as e:
+            e.set_option("boot_partials", partials)
+            e.upload_ind_major(p).commit()
+            S, Cn = e.run_batch(mult=mult, block_size=B)
+            s1 = [e.run_mult(m, B) for m in mult]
+        for r, m in enumerate(mult):
+            src = np.concatenate([np.repeat(np.arange(b * B, (b + 1) * B), int(k)) for b, k in enumerate(m)] + [np.zeros(0, int)])
+            if len(src) == 0:
+                assert not S[r].any() and not Cn[r].any(), (kernel, pd, r)
+                assert not s1[r][0].any() and not s1[r][1].any(), (kernel, pd, r)
+                continue
+            so, co = O.all_pairs(p, pairwise_del=pd, indep_geno=indep, site_src=src.astype(np.uint64), n_sites=len(src))
+            assert np.array_equal(Cn[r], co) and np.array_equal(s1[r][1], co)
+            assert rel_err(S[r], so) < RTOL and rel_err(s1[r][0], so) < RTOL
+
+
 # ---- site sharding: engines hold contiguous ranges of sites, (sum, cnt) are added -----------------------
 @pytest.mark.parametrize("kernel", ["mfma", "em_fast", "em_table", "stream"])
 def test_site_shards_add_up(kernel):
