@@ -57,8 +57,11 @@ for case in range(first, first + n_cases):
     path = os.path.join(tmp, "in_%d" % case + (".txt" if text else ".bin") + (".gz" if gz else ""))
     opener = (lambda q, m: gzip.open(q, m)) if gz else (lambda q, m: open(q, m))
     n_prefix = int(rng.integers(0, 3)) if text else 0
+    header = text and n_prefix > 0 and bool(rng.integers(0, 3) == 0)
     if text:
         with opener(path, "wt") as fh:
+            if header:  # a header is recognised by its non-numeric fields (read_data.cpp:62-70)
+                fh.write("chr\tpos\t" + "\t".join("ind%d" % i for i in range(n_ind * (3 if probs else 1))) + "\n")
             for s in range(n_sites):
                 pre = "".join("chr%d\t" % (s % 7) if k == 0 else "pos_%d\t" % s for k in range(n_prefix))
                 if probs:
@@ -95,9 +98,21 @@ for case in range(first, first + n_cases):
     if how == 1:
         args += ["--n_gpus", int(rng.choice([2, 3])), "--same_device"]
     elif how == 2:
-        args += ["--max_device_bytes", (512 << 20) + 256 * 128 * 128 * 8 + 64 * n_ind * n_ind + 400 * max(n_ind, 24) * max(400, n_sites // 3)]
+        n_pad = (n_ind + 127) // 128 * 128
+        args += ["--max_device_bytes", (512 << 20) + 256 * n_pad * n_pad * 8 + 64 * n_ind * n_ind + 400 * max(n_ind, 24) * max(400, n_sites // 3)]
     elif how == 3:
         args += ["--prep", str(rng.choice(["host", "device"]))]
+    labels = None
+    lab = int(rng.integers(0, 4))
+    if lab:
+        labels = ["s%d_%s" % (i, "ab*+#"[i % 5]) for i in range(n_ind)]
+        lpath = os.path.join(tmp, "labels_%d.txt" % case)
+        with open(lpath, "w") as fh:
+            if lab == 2:
+                fh.write("a header line\n")
+            for i, l in enumerate(labels):
+                fh.write(l + ("\tignored column" if i % 3 == 0 else "") + "\n")
+        args += ["--labelsH" if lab == 2 else "--labels", lpath]
     use_stdin = (not text) and (not gz) and bool(rng.integers(0, 4) == 0)
     tag = (case, n_ind, n_sites, "text" if text else "bin", "gz" if gz else "", [str(a) for a in args[10:]])
     # --- expected text
@@ -107,7 +122,7 @@ for case in range(first, first + n_cases):
             pp = O.load_text(path, n_ind, n_sites, probs, **kw)
         else:
             pp = O.prep_binary(raw, n_ind, n_sites, **kw)
-        exp = O.run_reference_flow(pp, score=O.score_matrix(avg), pairwise_del=pdel, indep_geno=indep, tot_sites=tot,
+        exp = O.run_reference_flow(pp, labels=labels, score=O.score_matrix(avg), pairwise_del=pdel, indep_geno=indep, tot_sites=tot,
                                    evol_model=model, n_boot_rep=n_boot, boot_block_size=B, seed=seed, n_threads=8)
         out = os.path.join(tmp, "out_%d.dist" % case)
         a = [str(x) for x in args]
@@ -127,11 +142,12 @@ for case in range(first, first + n_cases):
             dyadic = called_in or (call and call_thresh == 0.0)
             ca, cb = cells(got), cells(exp)
             # cells are compared BEFORE the logarithm of the evolutionary model: a pair at saturation (d = 1, or 3/4 under
-            # JC69) prints inf or 36.7 / 27.6 depending on the last bit of its sum, here as in the reference
+            # JC69) prints inf, nan or 36.7 / 27.6 depending on the last bit of its sum, here as in the reference
             back = (lambda x: x) if model == 0 else (lambda x: np.exp(-x)) if model == 1 else (lambda x: np.exp(-x * 4 / 3))
             with np.errstate(all="ignore"):
+                sat = (model > 0) & ((~np.isfinite(ca)) | (ca > 25)) & ((~np.isfinite(cb)) | (cb > 25))  # both at saturation
                 close = ca.shape == cb.shape and bool(np.all((np.abs(ca - cb) <= 2e-10) | (ca == cb) | (np.isnan(ca) & np.isnan(cb)) |
-                                                             (np.abs(back(ca) - back(cb)) <= 1e-9)))
+                                                             (np.abs(back(ca) - back(cb)) <= 1e-9) | sat))
             # (missing x missing sites without --pairwise_del put non-dyadic thirds into called-genotype sums too)
             if not close or (dyadic and pdel):
                 bad += 1
@@ -140,7 +156,7 @@ for case in range(first, first + n_cases):
                     print("   shapes", ca.shape, cb.shape, "lines", got.count("\n"), exp.count("\n"), flush=True)
                 else:
                     with np.errstate(all="ignore"):
-                        okm = (np.abs(ca - cb) <= 2e-10) | (ca == cb) | (np.isnan(ca) & np.isnan(cb)) | (np.abs(back(ca) - back(cb)) <= 1e-9)
+                        okm = (np.abs(ca - cb) <= 2e-10) | (ca == cb) | (np.isnan(ca) & np.isnan(cb)) | (np.abs(back(ca) - back(cb)) <= 1e-9) | sat
                     off = np.argwhere(~okm)
                     print("   %d cells off, first:" % len(off), [(tuple(int(x) for x in k), float(ca[tuple(k)]), float(cb[tuple(k)])) for k in off[:4]], flush=True)
                 if os.environ.get("FUZZ_KEEP"):
