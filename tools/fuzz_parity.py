@@ -42,8 +42,44 @@ for case in range(first, first + n_cases):
     t = N.Taus(case)
     maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
     tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, geom)
+    mode = int(rng.integers(0, 3))  # 0: one engine; 1: site ranges (partial multiplicities); 2: pair-tile shards
+    tag = tag + (("one", "site ranges", "pair tiles")[mode],)
     try:
-        with N.Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
+        if mode:
+            world = int(rng.integers(2, 5))
+            k_eff = n_eff // B if B else 0
+            if mode == 1:  # contiguous ranges of whole blocks; the tail (n_sites - n_eff) rides in the last range
+                cut_blocks = sorted(int(x) for x in rng.integers(0, k_eff + 1, size=world - 1))
+                cuts = [0] + [c * B for c in cut_blocks] + [n_sites]
+            mults = None
+            if n_rep:
+                mults = np.stack([np.bincount(m.astype(np.int64), minlength=k_eff) for m in maps]).astype(np.uint32)
+            n_p = N.n_pairs(n_ind)
+            S = np.zeros((n_rep + 1, n_p))
+            Cn = np.zeros((n_rep + 1, n_p), dtype=np.uint64)
+            for r in range(world):
+                if mode == 1:
+                    lo, hi = cuts[r], cuts[r + 1]
+                    if hi == lo:
+                        continue
+                    kw = {}
+                    sub = p[:, lo:hi]
+                    b_lo, b_hi = min(lo, n_eff) // B, min(hi, n_eff) // B
+                else:
+                    lo, hi, sub, b_lo, b_hi = 0, n_sites, p, 0, k_eff
+                    kw = dict(shard_rank=r, shard_world=world)
+                with N.Engine(n_ind, hi - lo, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom, **kw) as e:
+                    e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
+                    e.upload_ind_major(sub).commit()
+                    s0, c0 = e.run()
+                    S[0] += s0
+                    Cn[0] += c0
+                    if n_rep and b_hi > b_lo:
+                        sb, cb = e.run_batch(mult=np.ascontiguousarray(mults[:, b_lo:b_hi]), block_size=B)
+                        S[1:] += sb
+                        Cn[1:] += cb
+        else:
+          with N.Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
             e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
             e.upload_ind_major(p).commit()
             S, Cn = e.run_job(maps, B)
