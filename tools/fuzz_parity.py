@@ -42,6 +42,7 @@ for case in range(first, first + n_cases):
     t = N.Taus(case)
     maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
     tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, geom)
+    big = False
     mode = int(rng.integers(0, 3))  # 0: one engine; 1: site ranges (partial multiplicities); 2: pair-tile shards
     tag = tag + (("one", "site ranges", "pair tiles")[mode],)
     try:
@@ -54,6 +55,9 @@ for case in range(first, first + n_cases):
             mults = None
             if n_rep:
                 mults = np.stack([np.bincount(m.astype(np.int64), minlength=k_eff) for m in maps]).astype(np.uint32)
+                if n_eff <= 64 and n_ind <= 33 and rng.integers(0, 2):  # multiplicities no block map would give (many weight planes)
+                    mults = (mults * rng.integers(1, 3000, size=mults.shape)).astype(np.uint32)
+                    big = True
             n_p = N.n_pairs(n_ind)
             S = np.zeros((n_rep + 1, n_p))
             Cn = np.zeros((n_rep + 1, n_p), dtype=np.uint64)
@@ -85,8 +89,10 @@ for case in range(first, first + n_cases):
             S, Cn = e.run_job(maps, B)
         for m in sorted({0, n_rep // 2, n_rep}):
             src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
+            if m and big:
+                src = np.concatenate([np.repeat(np.arange(b * B, (b + 1) * B), int(k)) for b, k in enumerate(mults[m - 1])]).astype(np.uint64)
             so, co = O.all_pairs(p, score=score, pairwise_del=pdel, indep_geno=indep, site_src=src,
-                                 n_sites=n_sites if m == 0 else n_eff, n_threads=8)
+                                 n_sites=n_sites if m == 0 else (len(src) if big else n_eff), n_threads=8)
             ok = np.array_equal(Cn[m], co)
             fin = np.isfinite(so)
             ok = ok and np.array_equal(np.isfinite(S[m]), fin)
