@@ -21,12 +21,17 @@ static int fail(int code, const std::string &msg) {
   return code;
 }
 
+// A failed HIP call also leaves its code behind as the thread's "last error"; it is reported HERE, once, and cleared, so
+// that the hipGetLastError() after a later, unrelated kernel launch does not report it a second time (found by
+// tests/test_gpu_abi_misuse.py: an engine too large for the device poisoned the next engine's first launch).
 #define HIPCHK(call)                                                                       \
   do {                                                                                     \
     hipError_t _e = (call);                                                                \
-    if (_e != hipSuccess)                                                                  \
+    if (_e != hipSuccess) {                                                                \
+      (void)hipGetLastError();                                                             \
       return fail(_e == hipErrorOutOfMemory ? NGD_E_NOMEM : NGD_E_HIP,                     \
                   std::string(#call) + ": " + hipGetErrorString(_e));                      \
+    }                                                                                      \
   } while (0)
 
 struct ngd_engine {
@@ -230,6 +235,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   auto bail = [&](int code) {
     std::string keep = g_err;
     ngd_destroy(e);
+    (void)hipGetLastError();  // reported through `code`; not again by the next launch's check
     g_err = keep;
     return code;
   };

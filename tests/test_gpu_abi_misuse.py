@@ -1,0 +1,101 @@
+"""The C ABI called the way a careless host would: null pointers, geometry that does not fit, calls in the wrong
+order, out-of-range options.  Every one of them must come back as a negative code with a message in
+ngd_last_error() -- never a crash, an exit or a hang (the host converts codes to error(), the library
+itself must not take the process down) -- and the engine must still work afterwards."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments_are_codes_and_the_engine_survives():
+    import ngsdist_amd as N
+    from ngsdist_amd import _lib
+    L = _lib.load()
+    vp = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    u64p = C.POINTER(C.c_uint64)
+    u32p = C.POINTER(C.c_uint32)
+
+    def cfg(**kw):
+        c = _lib.NgdConfig()
+        c.n_ind, c.n_sites = kw.pop("n_ind", 6), kw.pop("n_sites", 40)
+        for k, v in enumerate(O.DEFAULT_SCORE):
+            c.score[k] = v
+        c.indep_geno, c.device, c.shard_world = 1, -1, 1
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def err(rc):
+        assert rc < 0, rc
+        assert len(L.ngd_last_error()) > 0
+
+    # ---- ngd_create
+    h = vp()
+    err(L.ngd_create(None, C.byref(h)))
+    err(L.ngd_create(C.byref(cfg()), None))
+    for bad in (dict(n_ind=1), dict(n_ind=0), dict(n_sites=0), dict(kernel=99), dict(variant=77), dict(exact_shapes=9),
+                dict(shard_rank=3, shard_world=2), dict(n_sites=1 << 40), dict(device=1000), dict(kernel=3, indep_geno=1),
+                dict(kernel=1, indep_geno=0), dict(n_ind=1 << 40, n_sites=1 << 40)):
+        h = vp()
+        err(L.ngd_create(C.byref(cfg(**bad)), C.byref(h)))
+        assert not h.value
+    # ---- a good engine, then misuse
+    n_ind, n_sites = 6, 40
+    h = vp()
+    assert L.ngd_create(C.byref(cfg()), C.byref(h)) == 0
+    n_pairs = n_ind * (n_ind - 1) // 2
+    s = np.zeros(4 * n_pairs)
+    c = np.zeros(4 * n_pairs, dtype=np.uint64)
+    sp, cp = s.ctypes.data_as(dp), c.ctypes.data_as(u64p)
+    err(L.ngd_run(h, None, 0, 0, sp, cp))  # nothing uploaded / committed
+    err(L.ngd_commit(None))
+    p = O.synth_indmajor(1, n_ind, n_sites)
+    err(L.ngd_upload_ind_major(h, None))
+    err(L.ngd_upload_sites(h, p.ctypes.data_as(dp), 30, 20))  # 30 + 20 > n_sites
+    rc = L.ngd_upload_ind_major(h, p.ctypes.data_as(dp))
+    assert rc == 0, (rc, L.ngd_last_error())
+    assert L.ngd_commit(h) == 0
+    err(L.ngd_upload_ind_major(h, p.ctypes.data_as(dp)))  # write-once
+    err(L.ngd_synth_fill(h, 1, 0.0))
+    maps = np.array([0, 1, 2, 3], dtype=np.uint64)
+    mp = maps.ctypes.data_as(u64p)
+    err(L.ngd_run(None, None, 0, 0, sp, cp))
+    err(L.ngd_run(h, mp, 4, 0, sp, cp))        # block size 0
+    err(L.ngd_run(h, mp, 0, 10, sp, cp))       # no blocks
+    err(L.ngd_run(h, mp, 4, 11, sp, cp))       # 44 sites > 40
+    err(L.ngd_run(h, mp, 1 << 62, 1 << 62, sp, cp))  # overflowing product
+    badmap = np.array([0, 1, 2, 9], dtype=np.uint64)
+    err(L.ngd_run(h, badmap.ctypes.data_as(u64p), 4, 10, sp, cp))
+    err(L.ngd_run_batch(h, None, 2, 4, 10, sp, cp))
+    err(L.ngd_run_batch(h, mp, 0, 4, 10, sp, cp))
+    err(L.ngd_run_job(h, None, 2, 4, 10, sp, cp))
+    mult = np.ones(4, dtype=np.uint32)
+    err(L.ngd_run_mult(h, None, 4, 10, sp, cp))
+    err(L.ngd_run_mult(h, mult.ctypes.data_as(u32p), 5, 10, sp, cp))
+    err(L.ngd_run_mult_batch(h, None, 1, 4, 10, sp, cp))
+    err(L.ngd_run_mult_batch(h, mult.ctypes.data_as(u32p), 0, 4, 10, sp, cp))
+    err(L.ngd_run_device(h, None, 0, 0, None, None))
+    err(L.ngd_run_job_device(h, mp, 1, 4, 10, None, None))
+    err(L.ngd_set_option(h, 9999, 1))
+    err(L.ngd_set_option(h, 0, 7))   # NGD_OPT_BOOT_PARTIALS is 0, 1 or 2
+    err(L.ngd_set_option(None, 0, 1))
+    err(L.ngd_last_timing(h, None))
+    err(L.ngd_last_em_work(None, None, None))
+    err(L.ngd_drop_caches(None))
+    err(L.ngd_finish(None, cp, 3, 0, 1, sp))
+    err(L.ngd_finish(sp, cp, 3, 0, 7, sp))
+    # ---- still in working order: the plain run and a replicate against the oracle
+    assert L.ngd_run(h, None, 0, 0, sp, cp) == 0
+    so, co = O.all_pairs(p)
+    assert np.array_equal(c[:n_pairs], co) and np.allclose(s[:n_pairs], so, rtol=1e-12)
+    assert L.ngd_run(h, mp, 4, 10, sp, cp) == 0
+    so, co = O.all_pairs(p, site_src=O.boot_site_src(maps, 10))
+    assert np.array_equal(c[:n_pairs], co) and np.allclose(s[:n_pairs], so, rtol=1e-12)
+    L.ngd_destroy(h)
+    L.ngd_destroy(None)  # a no-op, like free(NULL)
