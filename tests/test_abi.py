@@ -127,3 +127,37 @@ def test_shard_loads_are_balanced(lib):
                 r = lib.ngd_shard_of_pair(n, ti * 128, min(n - 1, tj * 128 + 1 if tj > ti else ti * 128 + 1), world)
                 load[r] += 36 if ti == tj else 64
         assert max(load) / (sum(load) / world) < 1.03
+
+
+def test_finish_and_format_from_several_threads_at_once():
+    """ngd_finish / ngd_format_matrix share one persistent thread pool; a caller that finds it busy does its work on its
+    own thread (the C++ host calls them from one thread per device).  Same bits from every thread."""
+    import threading
+
+    import ngsdist_amd as N
+    rng = np.random.default_rng(11)
+    n = 1 << 18  # above the pool's threshold
+    cnt = rng.integers(1, 1000, size=n).astype(np.uint64)
+    s = rng.random(n) * cnt * 0.7
+    with np.errstate(all="ignore"):
+        want = O.finish(s, cnt, 0, 2)
+    n_ind = 300
+    d = rng.random(n_ind * (n_ind - 1) // 2)
+    labels = ["ind%d" % i for i in range(n_ind)]
+    want_txt = N.format_matrix(d, labels)
+    out, txt = [None] * 6, [None] * 6
+
+    def work(k):
+        for _ in range(5):
+            with np.errstate(all="ignore"):
+                out[k] = N.finish(s, cnt, 0, 2)
+            txt[k] = N.format_matrix(d, labels)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(6):
+        assert np.array_equal(out[k], want, equal_nan=True)
+        assert txt[k] == want_txt
