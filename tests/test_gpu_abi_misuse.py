@@ -99,3 +99,41 @@ def test_bad_arguments_are_codes_and_the_engine_survives():
     assert np.array_equal(c[:n_pairs], co) and np.allclose(s[:n_pairs], so, rtol=1e-12)
     L.ngd_destroy(h)
     L.ngd_destroy(None)  # a no-op, like free(NULL)
+
+
+def test_engines_give_their_device_memory_back():
+    """create / upload / every kind of run (plain, bootstrap by partials and by passes, EM batch) / destroy, twenty times,
+    error exits included: the device's free memory comes back to where it was."""
+    import ngsdist_amd as N
+    from ngsdist_amd import _lib
+    L = _lib.load()
+    free0, tot = C.c_uint64(), C.c_uint64()
+
+    def free_now():
+        assert L.ngd_device_memory(-1, C.byref(free0), C.byref(tot)) == 0
+        return free0.value
+
+    n_ind, n_sites, B = 130, 3000, 10
+    p = O.synth_indmajor(3, n_ind, n_sites, miss_frac=0.05)
+    maps = np.stack([N.Taus(r).block_map(n_sites // B) for r in range(5)])
+    with N.Engine(n_ind, n_sites) as e:  # warm the runtime up (its own pools) before taking the baseline
+        e.upload_ind_major(p).commit().run()
+    base = free_now()
+    for it in range(20):
+        kernel = ("mfma", "stream", "em_table", "em_fast")[it % 4]
+        with N.Engine(n_ind, n_sites, indep_geno=kernel in ("mfma", "stream"), kernel=kernel, pairwise_del=bool(it & 1)) as e:
+            e.set_option("boot_partials", it % 3 != 0)
+            e.upload_ind_major(p).commit()
+            e.run()
+            e.run_job(maps, B)
+            e.run(maps[0], B)
+        with pytest.raises(N.NgdError):
+            N.Engine(n_ind, 1 << 40)  # far too large: the pieces allocated before the failure are freed again
+        bad = p.copy()
+        bad[3, 7, 1] = np.nan
+        with N.Engine(n_ind, n_sites) as e:
+            e.upload_raw_sites(np.ascontiguousarray(bad.transpose(1, 0, 2)), 0)
+            with pytest.raises(N.NgdError):
+                e.commit()  # "NaN found!"
+    leaked = base - free_now()
+    assert leaked < (64 << 20), "device memory not returned: %d MiB" % (leaked >> 20)
