@@ -40,6 +40,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <ctime>
 #include <string>
 #include <thread>
@@ -371,6 +372,135 @@ static void parallel_for(unsigned n_threads, uint64_t n, uint64_t min_n, F fn) {
 }
 
 // ---------------------------------------------------------------------------
+// BGZF text input (the blocked gzip that bgzip / htslib / ANGSD write: a series of gzip members of at most 64 KB, each
+// with its compressed size in a 'BC' extra field).  zlib's gzread -- the reference's reader, gen_func.cpp:208-223 --
+// inflates such a file like any other .gz, one member after the other on one thread; the members being independent, here
+// they are inflated on --n_threads threads, a few hundred at a time, CRCs checked as gzread checks them.  gets() has
+// gzgets' semantics, so everything downstream (line splitting, headers, premature / missing EOF) is the same code.
+struct BgzfText {
+  int fd = -1;
+  uint64_t size = 0, off = 0;  // file size; offset of the first block not yet inflated
+  std::vector<unsigned char> comp;
+  std::vector<char> text;      // the inflated blocks of the current batch
+  size_t cur = 0;
+  bool hit_eof = false, bad = false;
+  unsigned n_threads = 1;
+  static constexpr size_t kBatch = 16u << 20;  // compressed bytes per batch
+
+  // size of the block at q (at least 18 bytes readable), 0 if it is not a BGZF block
+  static uint32_t block_size(const unsigned char *q, size_t avail) {
+    if (avail < 18 || q[0] != 0x1f || q[1] != 0x8b || q[2] != 8 || !(q[3] & 4)) return 0;
+    const uint32_t xlen = q[10] | (uint32_t)q[11] << 8;
+    if (12 + (size_t)xlen > avail) return 0;
+    for (uint32_t x = 0; x + 4 <= xlen;) {
+      const unsigned char *f = q + 12 + x;
+      const uint32_t slen = f[2] | (uint32_t)f[3] << 8;
+      if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) return (f[4] | (uint32_t)f[5] << 8) + 1u;
+      x += 4 + slen;
+    }
+    return 0;
+  }
+  static BgzfText *open_if_bgzf(const char *path, unsigned n_threads) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    unsigned char head[64];
+    const ssize_t n = pread(fd, head, sizeof(head), 0);
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || n < 18 || block_size(head, (size_t)n) < 26) {
+      close(fd);
+      return nullptr;
+    }
+    BgzfText *b = new BgzfText();
+    b->fd = fd;
+    b->size = (uint64_t)st.st_size;
+    b->n_threads = std::max(1u, n_threads);
+    return b;
+  }
+  ~BgzfText() { if (fd >= 0) close(fd); }
+
+  // inflates the next batch of blocks into `text`; false when the file is used up (or damaged: bad)
+  bool fill() {
+    text.clear();
+    cur = 0;
+    while (text.empty()) {
+      if (off >= size || bad) return false;
+      const size_t want = (size_t)std::min<uint64_t>(kBatch, size - off);
+      comp.resize(want);
+      size_t got = 0;
+      while (got < want) {
+        const ssize_t r = pread(fd, comp.data() + got, want - got, (off_t)(off + got));
+        if (r <= 0) { bad = true; return false; }
+        got += (size_t)r;
+      }
+      struct Blk { size_t in, in_len, out; uint32_t isize, crc; };
+      std::vector<Blk> blks;
+      size_t q = 0, total = 0;
+      while (q + 18 <= want) {
+        const uint32_t bs = block_size(comp.data() + q, want - q);
+        if (!bs) { bad = true; return false; }  // not a BGZF block where one must start
+        if (q + bs > want) break;               // the batch ends inside this block: it opens the next batch
+        const uint32_t xlen = comp[q + 10] | (uint32_t)comp[q + 11] << 8;
+        if (bs < 20 + xlen) { bad = true; return false; }
+        const unsigned char *t = comp.data() + q + bs - 8;
+        Blk b;
+        b.in = q + 12 + xlen;
+        b.in_len = bs - 20 - xlen;
+        b.crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        b.isize = t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        if (b.isize > (1u << 16)) { bad = true; return false; }
+        b.out = total;
+        total += b.isize;
+        blks.push_back(b);
+        q += bs;
+      }
+      if (q == 0) { bad = true; return false; }  // a block larger than what is left of the file
+      text.resize(total);
+      std::atomic<int> err{0};
+      parallel_for(n_threads, blks.size(), 8, [&](uint64_t lo, uint64_t hi) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) { err = 1; return; }
+        for (uint64_t k = lo; k < hi && !err; k++) {
+          const Blk &b = blks[k];
+          if (!b.isize) continue;
+          if (inflateReset(&zs) != Z_OK) { err = 1; break; }  // (one state per thread, re-armed for every block)
+          zs.next_in = comp.data() + b.in;
+          zs.avail_in = (uInt)b.in_len;
+          zs.next_out = (Bytef *)text.data() + b.out;
+          zs.avail_out = b.isize;
+          const int rc = inflate(&zs, Z_FINISH);
+          if (rc != Z_STREAM_END || zs.avail_out != 0 ||
+              crc32(crc32(0L, Z_NULL, 0), (const Bytef *)text.data() + b.out, b.isize) != b.crc)
+            err = 1;
+        }
+        inflateEnd(&zs);
+      });
+      if (err) { bad = true; text.clear(); return false; }
+      off += q;
+    }
+    return true;
+  }
+  char *gets(char *buf, int len) {  // gzgets: up to len-1 characters, through the first newline
+    int w = 0;
+    while (w < len - 1) {
+      if (cur == text.size() && !fill()) { hit_eof = true; break; }
+      const char *src = text.data() + cur;
+      const size_t want = std::min(text.size() - cur, (size_t)(len - 1 - w));
+      const char *nl = (const char *)memchr(src, '\n', want);
+      const size_t take = nl ? (size_t)(nl - src) + 1 : want;
+      memcpy(buf + w, src, take);
+      w += (int)take;
+      cur += take;
+      if (nl) break;
+    }
+    if (!w) return nullptr;
+    buf[w] = '\0';
+    return buf;
+  }
+  bool eof() const { return hit_eof && !bad; }
+};
+
+// ---------------------------------------------------------------------------
 // one engine, destroyed with its scope
 struct Engine {
   ngd_engine *h = nullptr;
@@ -396,6 +526,9 @@ struct Engine {
 struct Loader {
   const Pars &p;
   gzFile fh = nullptr;
+  std::unique_ptr<BgzfText> bg;  // text input that turned out to be BGZF: inflated on several threads instead of by fh
+  char *text_gets(char *buf, int len) { return bg ? bg->gets(buf, len) : gzgets(fh, buf, len); }
+  bool text_eof() { return bg ? bg->eof() : gzeof(fh) != 0; }
   int raw_fd = -1;
   uint64_t raw_off = 0, raw_size = 0;
   uint64_t done = 0;  // sites of the whole input consumed by earlier parts
@@ -409,6 +542,10 @@ struct Loader {
 Loader::Loader(const Pars &pars, uint64_t first_site) : p(pars) {
   fh = open_gz(p.in_geno, p.in_bin ? "rb" : "r");
   if (!fh) die("read_geno", "cannot open GENO file!");
+  if (!p.in_bin && strcmp(p.in_geno, "-") != 0 && p.n_threads > 1) {  // (on one thread gzread does the same job)
+    bg.reset(BgzfText::open_if_bgzf(p.in_geno, p.n_threads));
+    if (bg && p.verbose >= 2) fprintf(stderr, "> BGZF input: blocks are inflated on %u thread(s)\n", bg->n_threads);
+  }
   // A binary GL file that is a plain regular file (the usual case; gzread would only copy it through) is read
   // with pread() on several threads straight into the destination: one thread moves ~12 GB/s out of the page
   // cache, which is less than the copy to the device and the preparation kernel take.
@@ -520,7 +657,7 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
       out.clear();
       *hit_end = false;
       while (out.size() < max_lines) {
-        if (gzgets(fh, line.data(), (int)line.size()) == nullptr) { *hit_end = true; break; }
+        if (text_gets(line.data(), (int)line.size()) == nullptr) { *hit_end = true; break; }
         chomp(line.data());
         out.emplace_back(line.data());
       }
@@ -549,7 +686,7 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
       }
       struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{reader};
       if (lines.empty()) {
-        if (gzeof(fh)) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+        if (text_eof()) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
         die("read_geno", "cannot read GZip GENO file. Check GENO file and number of sites!");
       }
       parallel_for(p.n_threads, lines.size(), 1, [&](uint64_t lo, uint64_t hi) {
@@ -620,9 +757,15 @@ void Loader::finish(bool check_eof) {
     if (check_eof && raw_off != raw_size) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
     close(raw_fd);
   } else {
-    char one;
-    gzread(fh, &one, 1);
+    char one[2];
+    if (bg) {
+      if (bg->gets(one, 2) != nullptr || !bg->eof())
+        die("read_geno", bg->bad ? "cannot read GZip GENO file. Check GENO file and number of sites!"
+                                 : "GENO file not at EOF. Check GENO file and number of sites!");
+    } else {
+    gzread(fh, one, 1);
     if (!gzeof(fh)) die("read_geno", "GENO file not at EOF. Check GENO file and number of sites!");
+    }
   }
   gzclose(fh);
 }

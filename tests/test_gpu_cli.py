@@ -328,3 +328,42 @@ def test_data_set_larger_than_the_device_goes_through_in_ranges(tmp_path):
         parts = cli(tmp_path, *gl, "--max_device_bytes", tiny, *extra, name="p2.dist")
         a, b = cells(whole), cells(parts)
         assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-10)
+
+
+def _write_bgzf(path, data, block=0xff00):
+    """blocked gzip as bgzip / htslib / ANGSD write it"""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        for k in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if k is None else data[k:k + block]
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                     + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+
+def test_bgzf_text_is_inflated_on_several_threads_and_prints_the_same_bytes(tmp_path):
+    """a .gz that is BGZF (independent members of <= 64 KB) goes through the block-parallel reader when --n_threads > 1;
+    everything downstream is the same code: same bytes as the plain .gz and as the oracle's flow, lines that straddle
+    blocks, the reference's EOF errors"""
+    path, lpath, labels = _testA_like(tmp_path)
+    data = gzip.open(path, "rb").read()
+    p = O.load_text(path, 24, 10000, in_probs=False)
+    exp = O.run_reference_flow(p, labels=labels, seed=12345, n_threads=8, n_boot_rep=2, boot_block_size=10)
+    base = ["--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345, "--n_boot_rep", 2, "--boot_block_size", 10]
+    for block in (0xff00, 777):
+        bz = str(tmp_path / ("b%d.geno.gz" % block))
+        _write_bgzf(bz, data, block)
+        for thr in (1, 5, 16):
+            r = subprocess.run([BIN, "--geno", bz, "--n_threads", str(thr), "--out", str(tmp_path / "b.dist"), "--verbose", "2"]
+                               + [str(a) for a in base], capture_output=True)
+            assert r.returncode == 0, r.stderr.decode()
+            assert (b"BGZF input" in r.stderr) == (thr > 1)
+            assert open(str(tmp_path / "b.dist")).read() == exp
+    r = subprocess.run([BIN, "--geno", bz, "--n_threads", "4", "--n_ind", "24", "--n_sites", "10001", "--out", str(tmp_path / "x")],
+                       capture_output=True)
+    assert r.returncode != 0 and b"premature EOF" in r.stderr
+    r = subprocess.run([BIN, "--geno", bz, "--n_threads", "4", "--n_ind", "24", "--n_sites", "9999", "--out", str(tmp_path / "x")],
+                       capture_output=True)
+    assert r.returncode != 0 and b"not at EOF" in r.stderr

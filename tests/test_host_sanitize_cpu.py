@@ -37,6 +37,19 @@ def run(san_bin, tmp_path, args, stdin=None, ok=True):
     return open(out).read() if ok else err
 
 
+def write_bgzf(path, data, block=0xff00, level=6):
+    """blocked gzip as bgzip / htslib write it: members of at most 64 KB with their size in a 'BC' extra field"""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        for k in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if k is None else data[k:k + block]  # (None: the empty end-of-file block)
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = c.compress(chunk) + c.flush()
+            fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25)
+                     + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+
+
 def n_rows(text):
     return sum(1 for l in text.split("\n") if l.count("\t") > 1)
 
@@ -91,5 +104,34 @@ def test_readers_ranges_bootstrap_and_printing_under_sanitizers(san_bin, tmp_pat
         bad.tofile(nb)
         run(san_bin, tmp_path, ["--geno", nb, "--probs", "--n_ind", n_ind, "--n_sites", n_sites], ok=False)
         case += 1
+    # ---- BGZF text: the same lines, inflated block-parallel; small blocks so that lines straddle them
+    n_ind, n_sites = 24, 1500
+    lines = ["chr\tpos\t" + "\t".join("i%d" % i for i in range(n_ind))]
+    for s_ in range(n_sites):
+        lines.append("" if s_ == 7 else "c\t%d\t" % s_ + "\t".join(str(int(x)) for x in rng.integers(-1, 3, size=n_ind)))
+    data = ("\n".join(lines) + "\n").encode()
+    plain = str(tmp_path / "plain.gz")
+    with gzip.open(plain, "wb") as fh:
+        fh.write(data)
+    args = ["--n_ind", n_ind, "--n_sites", n_sites, "--n_boot_rep", 2, "--boot_block_size", 10, "--seed", 3]
+    want = run(san_bin, tmp_path, ["--geno", plain] + args)
+    want2 = run(san_bin, tmp_path, ["--geno", plain, "--n_gpus", 2] + args)  # (the stub's numbers add up differently)
+    for block in (0xff00, 1000, 37):
+        bz = str(tmp_path / ("b%d.gz" % block))
+        write_bgzf(bz, data, block)
+        assert gzip.open(bz, "rb").read() == data  # (a valid multi-member gzip for everybody else)
+        for thr in (1, 7):
+            assert run(san_bin, tmp_path, ["--geno", bz, "--n_threads", thr] + args) == want
+            assert run(san_bin, tmp_path, ["--geno", bz, "--n_threads", thr, "--n_gpus", 2] + args) == want2
+        run(san_bin, tmp_path, ["--geno", bz, "--n_ind", n_ind, "--n_sites", n_sites + 3], ok=False)  # premature EOF
+        run(san_bin, tmp_path, ["--geno", bz, "--n_ind", n_ind, "--n_sites", n_sites - 3], ok=False)  # not at EOF
+    raw_b = bytearray(open(str(tmp_path / "b1000.gz"), "rb").read())
+    hurt = str(tmp_path / "hurt.gz")
+    raw_b[len(raw_b) // 2] ^= 0x55  # a damaged block in the middle
+    open(hurt, "wb").write(bytes(raw_b))
+    assert "GENO file" in run(san_bin, tmp_path, ["--geno", hurt, "--n_threads", 4] + args, ok=False)
+    cut = str(tmp_path / "cut.gz")
+    open(cut, "wb").write(open(str(tmp_path / "b1000.gz"), "rb").read()[:5000])  # the file ends inside a block
+    run(san_bin, tmp_path, ["--geno", cut, "--n_threads", 4] + args, ok=False)
     run(san_bin, tmp_path, ["--geno", "/nonexistent", "--n_ind", 3, "--n_sites", 3], ok=False)
     run(san_bin, tmp_path, ["--n_ind", 3, "--n_sites", 3], ok=False)

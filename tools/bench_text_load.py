@@ -18,17 +18,30 @@ with gzip.open(path, "wt", compresslevel=1) as fh:
         for row in x:
             fh.write("chr1\t%d\t" % s0 + "\t".join("%.6f" % v for v in row) + "\n")
 print("wrote %s (%.1f MB gz) in %.1f s" % (path, os.path.getsize(path) / 1e6, time.perf_counter() - t), flush=True)
+# the same text as BGZF (what bgzip / htslib / ANGSD write): members of <= 64 KB, inflated on --n_threads threads
+import struct, zlib
+bpath = os.path.join(out, "gl.bgzf.gz")
+data = gzip.open(path, "rb").read()
+with open(bpath, "wb") as fh:
+    for k in list(range(0, len(data), 0xff00)) + [None]:
+        chunk = b"" if k is None else data[k:k + 0xff00]
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                 + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+print("wrote %s (%.1f MB, %.1f MB of text)" % (bpath, os.path.getsize(bpath) / 1e6, len(data) / 1e6), flush=True)
+del data
 exe = os.path.join(ROOT, "ngsdist_amd", "bin", "ngsDist")
 res = []
-for nt in (1, 16):
-    o = os.path.join(out, "o%d.dist" % nt)
+for nt, path in ((1, path), (16, path), (1, bpath), (16, bpath)):
+    o = os.path.join(out, "o%d_%d.dist" % (nt, len(res)))
     t = time.perf_counter()
     r = subprocess.run([exe, "--geno", path, "--probs", "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--indep_geno",
                     "--n_threads", str(nt), "--out", o, "--verbose", "2"], check=True, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t
     res.append(open(o, "rb").read())
     load = [l for l in r.stderr.decode().splitlines() if "read + prepare" in l]
-    print("n_threads=%d: %.2f s end to end; %s" % (nt, dt, load[0].strip() if load else "?"), flush=True)
-print("outputs identical:", res[0] == res[1])
+    print("%s n_threads=%d: %.2f s end to end; %s" % (os.path.basename(path), nt, dt, load[0].strip() if load else "?"), flush=True)
+print("outputs identical:", all(r == res[0] for r in res))
 for f in os.listdir(out):  # keep gpurun_out/ small
     os.remove(os.path.join(out, f))

@@ -63,7 +63,27 @@ for case in range(first, first + n_cases):
     opener = (lambda q, m: gzip.open(q, m)) if gz else (lambda q, m: open(q, m))
     n_prefix = int(rng.integers(0, 3)) if text else 0
     header = text and n_prefix > 0 and bool(rng.integers(0, 3) == 0)
-    if text:
+    bgzf = text and bool(rng.integers(0, 2))  # blocked gzip (bgzip / htslib): inflated block-parallel by the host
+    if text and bgzf:
+        import io
+        import struct
+        import zlib
+        sio = io.StringIO()
+        if header:
+            sio.write("chr\tpos\t" + "\t".join("ind%d" % i for i in range(n_ind * (3 if probs else 1))) + "\n")
+        for s in range(n_sites):
+            pre = "".join("chr%d\t" % (s % 7) if k == 0 else "pos_%d\t" % s for k in range(n_prefix))
+            sio.write(pre + ("\t".join(repr(float(x)) for x in raw[s].reshape(-1)) if probs else "\t".join(str(int(x)) for x in g[s])) + "\n")
+        data = sio.getvalue().encode()
+        blk = int(rng.choice([0xff00, 4096, 61]))
+        with open(path, "wb") as fh:
+            for k in list(range(0, len(data), blk)) + [None]:
+                chunk = b"" if k is None else data[k:k + blk]
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                comp = c.compress(chunk) + c.flush()
+                fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp
+                         + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    elif text:
         with opener(path, "wt") as fh:
             if header:  # a header is recognised by its non-numeric fields (read_data.cpp:62-70)
                 fh.write("chr\tpos\t" + "\t".join("ind%d" % i for i in range(n_ind * (3 if probs else 1))) + "\n")
