@@ -497,6 +497,28 @@ struct BgzfText {
     buf[w] = '\0';
     return buf;
   }
+  // The next line as gzgets(buf, max_chars + 1) + chomp() would deliver it (a longer line comes in pieces, ONE trailing
+  // \n or \r is dropped), copied once, straight out of the inflated batch.
+  bool next_line(std::string &out, size_t max_chars) {
+    out.clear();
+    bool any = false;
+    while (out.size() < max_chars) {
+      if (cur == text.size() && !fill()) { hit_eof = true; break; }
+      const char *src = text.data() + cur;
+      const size_t want = std::min(text.size() - cur, max_chars - out.size());
+      const char *nl = (const char *)memchr(src, '\n', want);
+      const size_t take = nl ? (size_t)(nl - src) + 1 : want;
+      out.append(src, take);
+      cur += take;
+      any = true;
+      if (nl) break;
+    }
+    if (!any) return false;
+    const size_t z = out.find('\0');  // what strlen() in chomp() and the std::string made of the C string would see
+    if (z != std::string::npos) out.resize(z);
+    if (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+    return true;
+  }
   bool eof() const { return hit_eof && !bad; }
 };
 
@@ -656,6 +678,15 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
     auto read_lines_into = [&](std::vector<std::string> &out, uint64_t max_lines, bool *hit_end) {
       out.clear();
       *hit_end = false;
+      if (bg) {
+        std::string one;
+        while (out.size() < max_lines) {
+          if (!bg->next_line(one, line.size() - 1)) { *hit_end = true; break; }
+          out.emplace_back(std::move(one));
+          one.clear();  // (moved from: valid but unspecified)
+        }
+        return;
+      }
       while (out.size() < max_lines) {
         if (text_gets(line.data(), (int)line.size()) == nullptr) { *hit_end = true; break; }
         chomp(line.data());
