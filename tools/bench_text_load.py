@@ -41,6 +41,9 @@ for nt, path in ((1, path), (16, path), (1, bpath), (16, bpath)):
     dt = time.perf_counter() - t
     res.append(open(o, "rb").read())
     load = [l for l in r.stderr.decode().splitlines() if "read + prepare" in l]
+    for l in r.stderr.decode().splitlines():
+        if "text load:" in l:
+            print("   ", l.strip())
     print("%s n_threads=%d: %.2f s end to end; %s" % (os.path.basename(path), nt, dt, load[0].strip() if load else "?"), flush=True)
 print("outputs identical:", all(r == res[0] for r in res))
 for f in os.listdir(out):  # keep gpurun_out/ small
