@@ -237,3 +237,23 @@ def test_cfg4_full_size_block_additivity(cfg4_em):
     s_lo, _ = e.run(lo, B)
     s_hi, _ = e.run(hi, B)
     assert rel(s_lo + s_hi, 2 * full) < 1e-12
+
+
+@pytest.mark.parametrize("kernel,indep", [("mfma", True), ("stream", True), ("em_table", False), ("em_fast", False)])
+def test_tens_of_thousands_of_individuals(kernel, indep):
+    """n_ind = 16 000 (1.28e8 pairs, a 2 GB slab plane; 20 000 and 40 000 were run by hand at the end of round 2): index
+    widths and slab sizes -- pairs from the first, middle and last tiles against the oracle."""
+    n_ind, n_sites = 16000, 64
+    idx = [0, 1, 63, 64, 127, 128, n_ind // 2, n_ind - 129, n_ind - 2, n_ind - 1]
+    sub = np.concatenate([O.synth_indmajor(7, n_ind, n_sites, miss_frac=0.05, i0=i, n_sub=1) for i in idx])
+    with N().Engine(n_ind, n_sites, indep_geno=indep, kernel=kernel, pairwise_del=True) as e:
+        e.synth_fill(7, 0.05)
+        s, c = e.run()
+    so, co = O.all_pairs(sub, pairwise_del=True, indep_geno=indep)
+    k = 0
+    for a in range(len(idx)):
+        for b in range(a + 1, len(idx)):
+            g = N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)
+            assert c[g] == co[k]
+            assert abs(s[g] - so[k]) <= 1e-9 * abs(so[k])
+            k += 1
