@@ -125,6 +125,18 @@ def test_em(kernel, n_ind, n_sites, miss):
         assert rel_err(s, so) < RTOL
 
 
+def test_auto_picks_the_em_kernel_by_the_number_of_individuals():
+    """kernel = auto on the EM path: the per-pair kernel up to 32 individuals (one mostly empty 64 x 64 tile otherwise),
+    the table kernel above -- seen through ngd_last_em_work(), which only the table kernel fills in"""
+    for n_ind, table in ((24, False), (32, False), (33, True), (100, True)):
+        p = O.synth_indmajor(5, n_ind, 300)
+        with N().Engine(n_ind, 300, indep_geno=False, kernel="auto") as e:
+            s, c = e.upload_ind_major(p).commit().run()
+            assert (e.em_work()[1] > 0) == table, (n_ind, e.em_work())
+        so, co = O.all_pairs(p, indep_geno=False, n_threads=8)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
 @pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
 def test_score_matrix_need_not_be_symmetric(kernel):
     """the ABI takes any 3 x 3 score (params.score, ngsDist.hpp:20): the first individual of a pair indexes its rows
