@@ -52,6 +52,23 @@ WORKLOADS = {
 }
 
 
+def self_launch(n):
+    """Start `n` ranks of this script under torch.distributed.run on this node (127.0.0.1 rendezvous, a free port)
+    and return the launcher's exit code.  The children are new processes (never an exec of this one)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,7 +87,16 @@ def main():
                          "pair tiles over ranks (input replicated; disjoint results) -- both time the SAME job at every "
                          "N; or one matrix (bootstrap replicate) per GPU (weak scaling: the job grows with N); "
                          "auto = sites")
+    ap.add_argument("--pairwise_del", action="store_true",
+                    help="--pairwise_del with --miss_frac missing sites: counts differ per pair, so the N>1 flow also "
+                         "reduce-scatters the valid-site counts (not a BASELINE configuration)")
+    ap.add_argument("--miss_frac", type=float, default=0.0, help="fraction of exact (1/3,1/3,1/3) sites in the input")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process touches neither torch nor the GPU; it starts the
+        # N ranks as fresh children (one process per GPU, torch.distributed.run) and relays their output and exit code
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch  # first: one HIP runtime in the process (see ngsdist_amd/_lib.py)
@@ -113,6 +139,9 @@ def main():
     if world == 1:
         shard = "none"
     by_sites, by_reps = shard == "sites", shard == "replicates"
+    pdel = args.pairwise_del
+    if pdel and by_reps:
+        raise SystemExit("bench.py: --pairwise_del is wired for --shard sites|pairs")
     if by_reps:
         if W["n_boot"]:
             raise SystemExit("bench.py: --shard replicates is for the single-matrix workloads")
@@ -128,14 +157,14 @@ def main():
         n_units = n_eff // unit
         lo = (n_units * rank // world) * unit
         hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
-        eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank)
-        eng.synth_fill(W["seed"], 0.0, site0=lo)
+        eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel)
+        eng.synth_fill(W["seed"], args.miss_frac, site0=lo)
         blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
     else:
         lo, hi = 0, n_sites
-        eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank,
+        eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
                        shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world)
-        eng.synth_fill(W["seed"], 0.0)
+        eng.synth_fill(W["seed"], args.miss_frac)
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
@@ -170,11 +199,19 @@ def main():
         chunk, c_lo, c_hi = share_of(total, rank, world)
         d_flat = torch.zeros(world * chunk, dtype=torch.float64, device=dev)  # the engine's (partial) sums
         d_all = d_flat[:total].view(n_mat, n_pairs)
-        d_call = torch.zeros((n_mat, n_pairs), dtype=torch.int64, device=dev)
-        # no --pairwise_del in these workloads: a cell's count is the number of sites its matrix visits
+        # the engine's valid-site counts (ngsDist.cpp:362): per rank its own sites' / its own pairs' share
+        d_cflat = torch.zeros(world * chunk, dtype=torch.int64, device=dev)
+        d_call = d_cflat[:total].view(n_mat, n_pairs)
+        # without --pairwise_del a cell's count is the number of sites its matrix visits: no exchange needed
         cnt_flat = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
         cnt_flat[0, :] = n_sites
         cnt_flat = cnt_flat.reshape(-1)
+        if pdel:
+            h_call = torch.empty(total, dtype=torch.int64).pin_memory()
+            if world > 1:
+                d_cmine = torch.empty(chunk, dtype=torch.int64, device=dev)
+                h_cmine = torch.empty(chunk, dtype=torch.int64).pin_memory()
+                h_cflat = torch.empty(world * chunk, dtype=torch.int64).pin_memory() if not on_gpu else None
         if world > 1:
             d_mine = torch.empty(chunk, dtype=torch.float64, device=dev)
             h_mine, h_dist_mine = pin(chunk), pin(chunk)
@@ -241,13 +278,16 @@ def main():
             # the next is in flight
             copy_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(copy_stream):
+                if pdel:
+                    h_call.copy_(d_cflat[:total], non_blocking=True)
                 for c, (a, b) in enumerate(chunks):
                     h_all[a:b].copy_(d_all[a:b], non_blocking=True)
                     chunk_ev[c].record(copy_stream)
+            cnts = h_call.numpy().view(np.uint64) if pdel else cnt_flat
             with np.errstate(all="ignore"):
                 for c, (a, b) in enumerate(chunks):
                     chunk_ev[c].synchronize()
-                    N.finish(h_all[a:b].numpy().reshape(-1), cnt_flat[a * n_pairs:b * n_pairs], 0, W["evol_model"],
+                    N.finish(h_all[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], 0, W["evol_model"],
                              out=dist_all[a:b].reshape(-1))
             last["dist"] = dist_all[-1]
             return
@@ -256,13 +296,20 @@ def main():
         if on_gpu:
             scatter_sum(d_flat, d_mine)
             h_mine.copy_(d_mine, non_blocking=True)
+            if pdel:  # --pairwise_del: the valid-site counts of the ranks' site ranges add up the same way
+                scatter_sum(d_cflat, d_cmine)
+                h_cmine.copy_(d_cmine, non_blocking=True)
             # also: the collective has read d_flat before the engine (its own stream) may write it again
             torch.cuda.current_stream().synchronize()
         else:
             h_flat.copy_(d_flat)
             scatter_sum(h_flat, h_mine)
+            if pdel:
+                h_cflat.copy_(d_cflat)
+                scatter_sum(h_cflat, h_cmine)
+        cnts = h_cmine.numpy().view(np.uint64)[:c_hi - c_lo] if pdel else cnt_flat[c_lo:c_hi]
         with np.errstate(all="ignore"):
-            N.finish(h_mine.numpy()[:c_hi - c_lo], cnt_flat[c_lo:c_hi], 0, W["evol_model"],
+            N.finish(h_mine.numpy()[:c_hi - c_lo], cnts, 0, W["evol_model"],
                      out=h_dist_mine.numpy()[:c_hi - c_lo])
         if on_gpu:
             d_dist_mine.copy_(h_dist_mine, non_blocking=True)
@@ -289,6 +336,8 @@ def main():
             gather_matrices(d_all if on_gpu else h_all, d_dist if on_gpu else h_dist)
         else:
             scatter_sum(d_flat if on_gpu else h_flat, d_mine if on_gpu else h_mine)
+            if pdel:
+                scatter_sum(d_cflat if on_gpu else h_cflat, d_cmine if on_gpu else h_cmine)
             gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
     for _ in range(args.warmup):
         step(False)
@@ -321,10 +370,11 @@ def main():
         from oracle import oracle as O
         # 4 individuals -> 6 pairs, every site of the LAST matrix of the step (full data or last replicate)
         idx = [0, 1, n_ind // 2, n_ind - 1]
-        sub = np.concatenate([O.synth_indmajor(W["seed"], n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+        sub = np.concatenate([O.synth_indmajor(W["seed"], n_ind, n_sites, miss_frac=args.miss_frac, i0=i, n_sub=1)
+                              for i in idx])
         src = None if maps[-1] is None else O.boot_site_src(maps[-1], W["block"])
         so, co = O.all_pairs(sub, indep_geno=W["indep"], site_src=src, n_sites=n_eff if src is not None else n_sites,
-                             n_threads=6)
+                             n_threads=6, pairwise_del=pdel)
         with np.errstate(all="ignore"):
             do = O.finish(so, co, 0, W["evol_model"])
         k = 0
@@ -444,7 +494,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: n_ind=%d n_sites=%d %s evol_model=%d n_boot_rep=%d boot_block_size=%d"
                                % (args.workload, n_ind, n_sites, "--indep_geno" if W["indep"] else "EM",
-                                  W["evol_model"], W["n_boot"], W["block"]),
+                                  W["evol_model"], W["n_boot"], W["block"])
+                               + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
+                                  if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "

@@ -50,7 +50,8 @@ def share_of(total, rank, world):
 
 def scatter_sum(flat_t, mine_t):
     """flat_t: [world * chunk] partial sums of every cell (padding zeroed); after the call mine_t ([chunk]) holds
-    the SUM over ranks of this rank's share.  One reduce-scatter."""
+    the SUM over ranks of this rank's share.  One reduce-scatter.  float64 distance sums, and with --pairwise_del
+    (ngsDist.cpp:335-338, :362) the int64 valid-site counts of the ranks' site ranges the same way."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         mine_t.copy_(flat_t[:mine_t.numel()])

@@ -233,6 +233,69 @@ def test_two_rank_job_reduce_scatter_finish_all_gather():
     assert sum(n for _, _, n in res) == 5 * 78  # the shares partition the job's cells
 
 
+def _pdel_worker(rank, world, port, n_ind, n_sites, q):
+    """--pairwise_del under site sharding: a pair's valid-site count is a sum over the ranks' site ranges like its
+    distance sum, so BOTH go through scatter_sum (one reduce-scatter each), every rank finishes its share with the
+    summed counts, and gather_cells puts the cells together (bench.py --pairwise_del, ngsDist.cpp:335-338, :362)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import ngsdist_amd as N
+    from ngsdist_amd.dist import gather_cells, scatter_sum, share_of
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(9)
+    g = rng.integers(0, 3, size=(n_ind, n_sites))
+    p = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(p, g[..., None], 1.0, axis=2)
+    p[rng.random((n_ind, n_sites)) < 0.2] = 1.0 / 3  # missing data: skipped per pair, so the rest stays dyadic
+    n_pairs = N.n_pairs(n_ind)
+    lo, hi = n_sites * rank // world, n_sites * (rank + 1) // world
+    s_r, c_r = O.all_pairs(np.ascontiguousarray(p[:, lo:hi]), pairwise_del=True)  # stand-in for the device kernels
+    chunk, c_lo, c_hi = share_of(n_pairs, rank, world)
+    flat = torch.zeros(world * chunk, dtype=torch.float64)
+    cflat = torch.zeros(world * chunk, dtype=torch.int64)
+    flat[:n_pairs] = torch.from_numpy(s_r)
+    cflat[:n_pairs] = torch.from_numpy(c_r.astype(np.int64))
+    mine, cmine = torch.empty(chunk, dtype=torch.float64), torch.empty(chunk, dtype=torch.int64)
+    scatter_sum(flat, mine)
+    scatter_sum(cflat, cmine)
+    dist_mine = torch.zeros(chunk, dtype=torch.float64)
+    with np.errstate(all="ignore"):
+        N.finish(mine.numpy()[:c_hi - c_lo], cmine.numpy().view(np.uint64)[:c_hi - c_lo], 0, 2,
+                 out=dist_mine.numpy()[:c_hi - c_lo])
+    every = torch.empty(world * chunk, dtype=torch.float64)
+    gather_cells(every, dist_mine)
+    s, c = O.all_pairs(p, pairwise_del=True)
+    with np.errstate(all="ignore"):
+        want = O.finish(s, c, 0, 2)
+    full_c = torch.empty(world * chunk, dtype=torch.int64)
+    gather_cells(full_c, cmine)
+    q.put((rank, bool(np.array_equal(every.numpy()[:n_pairs], want, equal_nan=True)),
+           bool(np.array_equal(full_c.numpy()[:n_pairs].astype(np.uint64), c)), int(c.min()), int(c.max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_site_shards_with_pairwise_del_counts():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pdel_worker, args=(r, 2, port, 14, 397, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    assert all(ok_d and ok_c for _, ok_d, ok_c, _, _ in res)
+    assert res[0][3] < res[0][4] < 397  # counts really differ from pair to pair
+
+
 def test_share_of_partitions_any_job_into_equal_buffers():
     os.environ.setdefault("NGD_NO_TORCH", "1")
     from ngsdist_amd.dist import share_of
