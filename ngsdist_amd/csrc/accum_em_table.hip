@@ -40,7 +40,7 @@ typedef double ngd_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile double ngd_lds_cvd;
 __device__ __forceinline__ double lds_b64(const double *p) { return *(ngd_lds_cvd *)p; }
 
-template <int CH>
+template <int CH, bool PACK = false>
 struct alignas(16) em_tables {
   static constexpr int RS = CH + 2;  // row-table stride in doubles: spreads the builders' stores over the banks, 16-B aligned
   double Qr[TS * RS];                // rows:    e^tole / R_t            [row][step]
@@ -48,6 +48,10 @@ struct alignas(16) em_tables {
   double Rc[CH * TS];                // columns: R_t                     [step][column]
   double Gc[3][CH * TS];             // columns: (score * f_t)[x]        [x][step][column]
   uint32_t more[2];                  // "some pair of the tile has not stopped yet", one word per round parity
+  // PACK (later rounds worked in packed units, below): per wavefront, the contributions of one unit on their way from
+  // the lanes that computed them to the lanes that own the pairs, and the unit's column list
+  double unit_c[PACK ? 8 * 64 : 2];
+  uint8_t unit_col[PACK ? 8 * 8 : 8];
 };
 
 // Workgroup barrier that waits for this wavefront's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the
@@ -128,10 +132,10 @@ __device__ __forceinline__ double rcp_nr(double a) {
 // One wavefront's share of a table round: steps tfirst+1 .. tfirst+SEG of its 64 individuals (lane = individual),
 // v = GL^tfirst.  One role per call, so that the whole share is one block of straight-line code: the SEG+2 power
 // sums and their reciprocals are independent of each other and the scheduler can keep the FP64 pipe full.
-template <int CH, int SEG, bool ROW>
-__device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, const double *g, const ngd_score &sc,
+template <int CH, int SEG, bool ROW, bool PACK>
+__device__ __forceinline__ void build_round(em_tables<CH, PACK> &L, const double *v, const double *g, const ngd_score &sc,
                                             uint32_t lane, uint32_t seg, int tfirst, bool miss) {
-  constexpr int RS = em_tables<CH>::RS;
+  constexpr int RS = em_tables<CH, PACK>::RS;
   const double E = 0x1.0041919b7ee34p+0;  // exp(0.001), the tolerance of ngsDist.cpp:349
   // pw = GL^(tfirst+k), A[k] its sum, r[k] = 1/A[k]; k = 1 .. SEG are the steps written.  Step k needs A and r of
   // k-1, k, k+1; f_k leaves as soon as r[k] is known and the powers are not kept, so that a step's live range is
@@ -180,6 +184,109 @@ __device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, c
   }
 }
 
+typedef __attribute__((address_space(3))) volatile double ngd_lds_vd;
+typedef __attribute__((address_space(3))) volatile uint8_t ngd_lds_vb;
+typedef __attribute__((address_space(3))) const volatile ngd_d2 ngd_lds_cvd2;
+
+// One row of the tile the plain way (lane = column): the row's CH thresholds are the same 16 bytes in every lane (one
+// ds_read_b128 per two steps), the column's R_t sit in registers (R2).  Pairs of `todo` bit r that stop within the
+// round add their term to accr and leave todo.
+template <int CH, bool WEIGHTED, bool PACK>
+__device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t rb /* row * RS */, uint32_t lane, int r,
+                                         const double (&R2)[CH], uint32_t &todo, double &accr, double wgt) {
+  ngd_d2 Q[CH / 2];
+#pragma unroll
+  for (int h = 0; h < CH / 2; h++) Q[h] = *(const ngd_d2 *)&L.Qr[rb + 2 * h];
+  const bool mine = (todo >> r) & 1;
+  uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+  uint32_t n = 0;
+#pragma unroll
+  for (int b = 0; b < CH / 8; b++) {
+    if (b && m == 0) break;  // every lane has stopped
+    scan8(m, n, R2[8 * b], R2[8 * b + 1], R2[8 * b + 2], R2[8 * b + 3], R2[8 * b + 4], R2[8 * b + 5], R2[8 * b + 6],
+          R2[8 * b + 7], Q[4 * b][0], Q[4 * b][1], Q[4 * b + 1][0], Q[4 * b + 1][1], Q[4 * b + 2][0], Q[4 * b + 2][1],
+          Q[4 * b + 3][0], Q[4 * b + 3][1]);
+  }
+  const int T = mine && n < (uint32_t)CH ? (int)n + 1 : 0;
+  const uint32_t ti = T ? T - 1 : 0;
+  const uint32_t a = rb + ti, b = ti * TS + lane;
+  double c = lds_b64(&L.Fr[0][a]) * lds_b64(&L.Gc[0][b]);
+  c = __builtin_fma(lds_b64(&L.Fr[1][a]), lds_b64(&L.Gc[1][b]), c);
+  c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
+  if (WEIGHTED) c = c * wgt;
+  if (T) {
+    accr = accr + c;
+    todo &= ~(1u << r);
+  }
+}
+
+// Later rounds, what the plain rows leave: the pairs still searching sit in a few COLUMNS (the individuals whose own
+// factor R_t has not come down yet: every row of such a column is still searching) plus a few stragglers, so a plain
+// row scan would run with ~15 of its 64 lanes.  A packed unit takes 8 of those columns x this wavefront's 8 rows:
+// lane = (column slot, row); both the row's thresholds and the column's R_t come from the tables by per-lane
+// address; the search and the term are the plain row's, instruction for instruction (same bits).  The terms then travel
+// inside the wavefront -- through its 512 bytes of unit_c -- to the lanes that own the pairs (lane = column), which
+// add them in the same order as ever: one term per pair and site, 0.0 from the slots that had nothing to add.
+template <int CH, bool WEIGHTED>
+__device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wave, uint32_t lane, uint32_t &todo,
+                                             double (&acc)[8], double wgt) {
+  constexpr int RS = em_tables<CH, true>::RS;
+  static_assert(CH % 8 == 0, "shape");
+  ngd_lds_vd *uc = (ngd_lds_vd *)&L.unit_c[wave * 64];
+  ngd_lds_vb *ul = (ngd_lds_vb *)&L.unit_col[wave * 8];
+  const uint32_t slot = lane >> 3, r = lane & 7;
+  const uint32_t rb = (wave * 8 + r) * RS;
+  uint64_t pm = __builtin_amdgcn_ballot_w64(todo != 0);  // columns with a pair still searching
+  while (pm) {
+    // this unit's columns: the first 8 set bits of pm, slot = rank among them
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+    const bool sel = ((pm >> lane) & 1) && rank < 8;
+    if (sel) ul[rank] = (uint8_t)lane;
+    const uint32_t n_col = (uint32_t)__builtin_popcountll(pm);
+    const bool valid = slot < n_col;  // (a wavefront's LDS operations execute in order: the list is there)
+    const uint32_t col = valid ? (uint32_t)ul[slot] : 0;
+    const uint32_t tb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(col << 2), (int)todo);
+    const bool mine = valid && ((tb >> r) & 1);
+    uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+    uint32_t n = 0;
+#pragma unroll
+    for (int b = 0; b < CH / 8; b++) {
+      if (b && m == 0) break;
+      double R[8];
+      ngd_d2 Q[4];
+#pragma unroll
+      for (int k = 0; k < 8; k++) R[k] = lds_b64(&L.Rc[(8 * b + k) * TS + col]);
+#pragma unroll
+      for (int h = 0; h < 4; h++) Q[h] = *(ngd_lds_cvd2 *)&L.Qr[rb + 8 * b + 2 * h];
+      scan8(m, n, R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], Q[0][0], Q[0][1], Q[1][0], Q[1][1], Q[2][0], Q[2][1],
+            Q[3][0], Q[3][1]);
+    }
+    const int T = mine && n < (uint32_t)CH ? (int)n + 1 : 0;
+    const uint32_t ti = T ? T - 1 : 0;
+    const uint32_t a = rb + ti, b = ti * TS + col;
+    double c = lds_b64(&L.Fr[0][a]) * lds_b64(&L.Gc[0][b]);
+    c = __builtin_fma(lds_b64(&L.Fr[1][a]), lds_b64(&L.Gc[1][b]), c);
+    c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
+    if (WEIGHTED) c = c * wgt;
+    const uint64_t done = __builtin_amdgcn_ballot_w64(T != 0);  // bit = 8 * slot + row
+    uc[lane] = T ? c : 0.0;
+    if (sel) {  // the owners of this unit's columns collect their 8 rows
+      ngd_lds_cvd2 *mail = (ngd_lds_cvd2 *)&L.unit_c[wave * 64 + rank * 8];
+      const ngd_d2 v0 = mail[0], v1 = mail[1], v2 = mail[2], v3 = mail[3];
+      acc[0] = acc[0] + v0[0];
+      acc[1] = acc[1] + v0[1];
+      acc[2] = acc[2] + v1[0];
+      acc[3] = acc[3] + v1[1];
+      acc[4] = acc[4] + v2[0];
+      acc[5] = acc[5] + v2[1];
+      acc[6] = acc[6] + v3[0];
+      acc[7] = acc[7] + v3[1];
+      todo &= ~((uint32_t)(done >> (rank * 8)) & 0xffu);
+    }
+    pm &= ~__builtin_amdgcn_ballot_w64(sel);
+  }
+}
+
 #if defined(NGD_EMT_STAMPS)  // diagnostic build: where a wavefront's cycles go (tools/em_stamps.py)
 #define EMT_STAMP(slot)                                                              \
   do {                                                                               \
@@ -196,17 +303,22 @@ __device__ __forceinline__ void build_round(em_tables<CH> &L, const double *v, c
 
 // NW wavefronts per workgroup (64 / NW rows each), CH steps per table round, WPS = waves per SIMD the
 // register allocation is held to (workgroups per CU x NW / 4)
-template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL>
+// PACK: from the second round of a site on, only the rows in which at least PACK_DENSE pairs are still searching are
+// scanned the plain way; the rest goes through packed_units()
+constexpr int PACK_DENSE = 24;
+
+template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK>
 __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     const double *__restrict__ PA, const uint32_t *__restrict__ ws, ngd_score sc, const ngd_tile *__restrict__ tiles,
     uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind, uint64_t n_sites_eff, uint64_t sites_per_slice,
     double *__restrict__ slab, unsigned long long *__restrict__ counters) {
   constexpr int RPW = TS / NW;  // rows per wavefront
-  constexpr int RS = em_tables<CH>::RS;
+  constexpr int RS = em_tables<CH, PACK>::RS;
+  static_assert(!PACK || (NW == 8 && WPS >= 4), "packed units: 8 wavefronts x 8 rows");
   // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
   constexpr int GR = WPS >= 4 ? 1 : 4;
   static_assert(RPW % GR == 0 && CH % 4 == 0 && (CH % 8 == 0 || CH % 8 == 4), "shape");
-  __shared__ em_tables<CH> L;
+  __shared__ em_tables<CH, PACK> L;
   const uint32_t tile = blockIdx.x % n_tiles;
   const uint32_t ks = blockIdx.x / n_tiles;
   const uint32_t I0 = tiles[tile].ti * TS, J0 = tiles[tile].tj * TS;
@@ -295,8 +407,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     for (int t0 = 0; t0 < MAX_ITER; t0 += CH, round++) {  // steps t0+1 .. t0+CH
       {
         const int tfirst = t0 + (int)seg * SEG;  // this wavefront's steps are tfirst+1 .. tfirst+SEG
-        if (is_row) build_round<CH, SEG, true>(L, v, g, sc, lane, seg, tfirst, miss);
-        else build_round<CH, SEG, false>(L, v, g, sc, lane, seg, tfirst, miss);
+        if (is_row) build_round<CH, SEG, true, PACK>(L, v, g, sc, lane, seg, tfirst, miss);
+        else build_round<CH, SEG, false, PACK>(L, v, g, sc, lane, seg, tfirst, miss);
 #pragma unroll
         for (int x = 0; x < 3; x++) v[x] *= gch[x];
       }
@@ -306,7 +418,25 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       // the other parity's word: every wavefront has read it (it is behind that read), it is next written after the
       // next round's first barrier
       if (tid == 0) L.more[(round & 1) ^ 1] = 0;
-      if (__builtin_amdgcn_ballot_w64(todo != 0)) {
+      if constexpr (PACK) {
+        if (__builtin_amdgcn_ballot_w64(todo != 0)) {
+          // rows scanned the plain way: all that have a pair in the first round, the dense ones later
+          const uint32_t least = t0 == 0 ? 1 : PACK_DENSE;
+          uint32_t rows = 0;
+#pragma unroll
+          for (int r = 0; r < RPW; r++)
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((todo >> r) & 1)) >= least) rows |= 1u << r;
+          if (rows) {
+            double R2[CH];
+#pragma unroll
+            for (int tt = 0; tt < CH; tt++) R2[tt] = lds_b64(&L.Rc[tt * TS + lane]);
+#pragma unroll
+            for (int r = 0; r < RPW; r++)
+              if ((rows >> r) & 1) scan_row<CH, WEIGHTED, PACK>(L, (wave * RPW + r) * RS, lane, r, R2, todo, acc[r], wgt);
+          }
+          if (t0 != 0) packed_units<CH, WEIGHTED>(L, wave, lane, todo, acc, wgt);
+        }
+      } else if (__builtin_amdgcn_ballot_w64(todo != 0)) {
         double R2[CH];
 #pragma unroll
         for (int tt = 0; tt < CH; tt++) R2[tt] = lds_b64(&L.Rc[tt * TS + lane]);
@@ -386,19 +516,20 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
                                double *slab, unsigned long long *d_counters) {
   if (!n_tiles64) return;
   const bool w = d_ws != nullptr, p = pairwise_del != 0;
-#define NGD_EMT(NW, CH, WPS, W, P)                                                                              \
-  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
+#define NGD_EMT(NW, CH, WPS, W, P, K)                                                                              \
+  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P, K>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
                      score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab, d_counters)
-#define NGD_EMT_WP(NW, CH, WPS)                                              \
-  do {                                                                       \
-    if (w) { if (p) NGD_EMT(NW, CH, WPS, true, true); else NGD_EMT(NW, CH, WPS, true, false); }   \
-    else   { if (p) NGD_EMT(NW, CH, WPS, false, true); else NGD_EMT(NW, CH, WPS, false, false); } \
+#define NGD_EMT_WP(NW, CH, WPS, K)                                                 \
+  do {                                                                             \
+    if (w) { if (p) NGD_EMT(NW, CH, WPS, true, true, K); else NGD_EMT(NW, CH, WPS, true, false, K); }   \
+    else   { if (p) NGD_EMT(NW, CH, WPS, false, true, K); else NGD_EMT(NW, CH, WPS, false, false, K); } \
   } while (0)
   switch (shape) {
-    default: NGD_EMT_WP(8, 16, 4); break;
-    case 1: NGD_EMT_WP(4, 16, 2); break;
-    case 2: NGD_EMT_WP(8, 12, 4); break;
-    case 3: NGD_EMT_WP(4, 12, 2); break;
+    default: NGD_EMT_WP(8, 16, 4, false); break;
+    case 1: NGD_EMT_WP(4, 16, 2, false); break;
+    case 2: NGD_EMT_WP(8, 12, 4, false); break;
+    case 3: NGD_EMT_WP(4, 12, 2, false); break;
+    case 4: NGD_EMT_WP(8, 16, 4, true); break;
   }
 #undef NGD_EMT_WP
 #undef NGD_EMT

@@ -190,7 +190,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
   if (cfg->exact_shapes > 2) return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never) or 2 (always)");
-  if (cfg->variant > 3) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
+  if (cfg->variant > 4) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
   const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
   if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
 
