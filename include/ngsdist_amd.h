@@ -66,7 +66,7 @@ typedef struct ngd_config {
   uint32_t shard_world; /*   ngd_shard_of_pair() gives it; 0/1 = everything   */
   /* Launch geometry; 0 = the measured defaults, which is what a host wants.  They change
    * speed only, never results beyond the order of additions over site slices. */
-  uint32_t variant;      /* NGD_KERNEL_EM_TABLE: workgroup shape 0..3 (accum_em_table.hip)            */
+  uint32_t variant;      /* NGD_KERNEL_EM_TABLE: workgroup shape 0..4 (accum_em_table.hip)            */
   uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8)  */
   uint32_t wg_target;    /* workgroups wanted per launch, from which n_slices is derived when it is 0 */
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 = always issue only the MFMA tiles a block   */

@@ -51,6 +51,9 @@ struct alignas(16) em_tables {
   // PACK (later rounds worked in packed units, below): per wavefront, the contributions of one unit on their way from
   // the lanes that computed them to the lanes that own the pairs, and the unit's column list
   double unit_c[PACK ? 8 * 64 : 2];
+  // bit i of word p: row i of the tile cannot stop at any of the steps the p-th row builder wrote this round
+  // (its own factor R_t is still >= e^tole there, and a column's is never below 1): the plain scan skips those steps
+  unsigned long long row_nostop[4];
   uint8_t unit_col[PACK ? 8 * 8 : 8];
 };
 
@@ -143,6 +146,7 @@ __device__ __forceinline__ void build_round(em_tables<CH, PACK> &L, const double
   // that form wanted 100+ VGPRs around the build and left the allocator no slack anywhere else).
   double pw[3] = {v[0], v[1], v[2]};
   double A[SEG + 2], r[SEG + 2];
+  bool nostop = true;
   A[0] = (pw[0] + pw[1]) + pw[2];
   r[0] = rcp_nr(A[0]);
 #pragma unroll
@@ -174,6 +178,9 @@ __device__ __forceinline__ void build_round(em_tables<CH, PACK> &L, const double
         double q = (E * (A[c] * A[c])) * (r[c + 1] * r[c - 1]);
         if (force) q = __builtin_inf();
         L.Qr[lane * RS + tt] = q;
+        // a pair stops where R(column) < q, and the R the column builders write is 1 or more up to a few units in
+        // the last place: below this q no column can stop
+        if (PACK) nostop = nostop && q <= 1.0 - 0x1p-40;
       } else {
         double rr = (A[c + 1] * A[c - 1]) * (r[c] * r[c]);
         if (force) rr = 0.0;
@@ -181,6 +188,10 @@ __device__ __forceinline__ void build_round(em_tables<CH, PACK> &L, const double
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (PACK && ROW) {
+    const unsigned long long none = __builtin_amdgcn_ballot_w64(nostop);
+    if (lane == 0) L.row_nostop[seg] = none;
   }
 }
 
@@ -191,28 +202,52 @@ typedef __attribute__((address_space(3))) const volatile ngd_d2 ngd_lds_cvd2;
 // One row of the tile the plain way (lane = column): the row's CH thresholds are the same 16 bytes in every lane (one
 // ds_read_b128 per two steps), the column's R_t sit in registers (R2).  Pairs of `todo` bit r that stop within the
 // round add their term to accr and leave todo.
+// skip: bit b = no pair of this row can stop in steps 8b+1 .. 8b+8 (row_nostop): that block is not searched.
+// The LDS reads of a row are issued so that a wavefront waits for ONE round trip per row, not three: the thresholds of
+// the second block go out before the first block is searched; the next row's first-block thresholds (rb_next, `pref`)
+// go out behind this row's six table reads for its terms, so the wait for those leaves them in flight.  QA holds the
+// first-block thresholds: put there by the previous row's call, or read here if `load`.  (Every read is volatile: issue
+// order = program order.)
 template <int CH, bool WEIGHTED, bool PACK>
-__device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t rb /* row * RS */, uint32_t lane, int r,
-                                         const double (&R2)[CH], uint32_t &todo, double &accr, double wgt) {
-  ngd_d2 Q[CH / 2];
-#pragma unroll
-  for (int h = 0; h < CH / 2; h++) Q[h] = *(const ngd_d2 *)&L.Qr[rb + 2 * h];
+__device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t rb /* row * RS */, uint32_t rb_next,
+                                         uint32_t lane, int r, const double (&R2)[CH], ngd_d2 (&QA)[4], uint32_t &todo,
+                                         double &accr, double wgt, uint32_t skip, bool load, bool pref) {
+  static_assert(CH == 16, "two blocks of eight steps");
   const bool mine = (todo >> r) & 1;
   uint64_t m = __builtin_amdgcn_ballot_w64(mine);
-  uint32_t n = 0;
+  ngd_d2 QB[4];
+  if (load) {
 #pragma unroll
-  for (int b = 0; b < CH / 8; b++) {
-    if (b && m == 0) break;  // every lane has stopped
-    scan8(m, n, R2[8 * b], R2[8 * b + 1], R2[8 * b + 2], R2[8 * b + 3], R2[8 * b + 4], R2[8 * b + 5], R2[8 * b + 6],
-          R2[8 * b + 7], Q[4 * b][0], Q[4 * b][1], Q[4 * b + 1][0], Q[4 * b + 1][1], Q[4 * b + 2][0], Q[4 * b + 2][1],
-          Q[4 * b + 3][0], Q[4 * b + 3][1]);
+    for (int h = 0; h < 4; h++) QA[h] = *(ngd_lds_cvd2 *)&L.Qr[rb + 2 * h];
   }
-  const int T = mine && n < (uint32_t)CH ? (int)n + 1 : 0;
+  // (also when the second block will be skipped: such a row is nearly always out of the round altogether, and an
+  // unconditional read keeps a branch and eight register moves out of every row)
+#pragma unroll
+  for (int h = 0; h < 4; h++) QB[h] = *(ngd_lds_cvd2 *)&L.Qr[rb + 8 + 2 * h];
+  uint32_t n = 8;  // steps survived (by the lanes in m; the others keep what they had when they stopped)
+  if (!(skip & 1)) {
+    n = 0;
+    scan8(m, n, R2[0], R2[1], R2[2], R2[3], R2[4], R2[5], R2[6], R2[7], QA[0][0], QA[0][1], QA[1][0], QA[1][1], QA[2][0],
+          QA[2][1], QA[3][0], QA[3][1]);
+  }
+  // second block skipped: the lanes that are still searching (n = 8) stay so
+  const uint32_t lim = (skip & 2) ? 8 : CH;
+  if (m != 0 && !(skip & 2))
+    scan8(m, n, R2[8], R2[9], R2[10], R2[11], R2[12], R2[13], R2[14], R2[15], QB[0][0], QB[0][1], QB[1][0], QB[1][1],
+          QB[2][0], QB[2][1], QB[3][0], QB[3][1]);
+  const int T = mine && n < lim ? (int)n + 1 : 0;
   const uint32_t ti = T ? T - 1 : 0;
   const uint32_t a = rb + ti, b = ti * TS + lane;
-  double c = lds_b64(&L.Fr[0][a]) * lds_b64(&L.Gc[0][b]);
-  c = __builtin_fma(lds_b64(&L.Fr[1][a]), lds_b64(&L.Gc[1][b]), c);
-  c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
+  const double f0 = lds_b64(&L.Fr[0][a]), g0 = lds_b64(&L.Gc[0][b]);
+  const double f1 = lds_b64(&L.Fr[1][a]), g1 = lds_b64(&L.Gc[1][b]);
+  const double f2 = lds_b64(&L.Fr[2][a]), g2 = lds_b64(&L.Gc[2][b]);
+  if (pref) {
+#pragma unroll
+    for (int h = 0; h < 4; h++) QA[h] = *(ngd_lds_cvd2 *)&L.Qr[rb_next + 2 * h];
+  }
+  double c = f0 * g0;
+  c = __builtin_fma(f1, g1, c);
+  c = __builtin_fma(f2, g2, c);
   if (WEIGHTED) c = c * wgt;
   if (T) {
     accr = accr + c;
@@ -367,7 +402,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   unsigned long long stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-  for (uint64_t s = s0; s < s1; s++) {
+  // (a 32-bit count in a scalar register: as a 64-bit bound the compiler kept s1 in vector registers and spilled it)
+  const uint32_t n_mine = s0 < s1 ? __builtin_amdgcn_readfirstlane((uint32_t)(s1 - s0)) : 0;
+  for (uint32_t si = 0; si < n_mine; si++) {
+    const uint64_t s = s0 + si;
     double wgt = 1.0;
     EMT_STAMP(0);  // loop overhead, end-of-site
     double g[3] = {gn[0], gn[1], gn[2]};
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]));  // the wait for the loads happens here
     EMT_STAMP(1);  // waiting for this site's likelihoods
 #endif
-    if (s + 1 < s1) load_site(s + 1, gn);  // in flight while this site is worked on
+    if (si + 1 < n_mine) load_site(s + 1, gn);  // in flight while this site is worked on
     if (WEIGHTED) {
       const uint32_t m = ws[s];
       if (m == 0) continue;  // site not drawn in this replicate (uniform across the workgroup)
@@ -427,12 +465,29 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
           for (int r = 0; r < RPW; r++)
             if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((todo >> r) & 1)) >= least) rows |= 1u << r;
           if (rows) {
+            // the row builders' verdicts on this wavefront's 8 rows: first / second block of eight steps
+            typedef const volatile __attribute__((address_space(3))) unsigned long long lds_cvu64;
+            unsigned long long ns[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) ns[p] = *(lds_cvu64 *)&L.row_nostop[p];
+            const unsigned long long nsa = ns[0] & ns[1], nsb = ns[2] & ns[3];
+            const uint32_t sh = (wave & 3) * 8;
+            const uint32_t ska = __builtin_amdgcn_readfirstlane((uint32_t)(wave < 4 ? nsa : nsa >> 32) >> sh) & 0xff;
+            const uint32_t skb = __builtin_amdgcn_readfirstlane((uint32_t)(wave < 4 ? nsb : nsb >> 32) >> sh) & 0xff;
             double R2[CH];
 #pragma unroll
             for (int tt = 0; tt < CH; tt++) R2[tt] = lds_b64(&L.Rc[tt * TS + lane]);
+            const uint32_t go = rows & ~(ska & skb);     // rows searched in this round
+            const uint32_t need_a = go & ~ska;           // ... that search their first block
+            const uint32_t load = need_a & ~(go << 1);   // ... and whose predecessor is not there to fetch its thresholds
+            const uint32_t pref = need_a >> 1;           // rows that fetch their successor's
+            ngd_d2 QA[4];
 #pragma unroll
             for (int r = 0; r < RPW; r++)
-              if ((rows >> r) & 1) scan_row<CH, WEIGHTED, PACK>(L, (wave * RPW + r) * RS, lane, r, R2, todo, acc[r], wgt);
+              if ((go >> r) & 1)
+                scan_row<CH, WEIGHTED, PACK>(L, (wave * RPW + r) * RS, (wave * RPW + r + 1) * RS, lane, r, R2, QA, todo,
+                                             acc[r], wgt, ((ska >> r) & 1) | (((skb >> r) & 1) << 1), (load >> r) & 1,
+                                             (pref >> r) & 1);
           }
           if (t0 != 0) packed_units<CH, WEIGHTED>(L, wave, lane, todo, acc, wgt);
         }
@@ -484,7 +539,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
           }
         }
       }
-      EMT_STAMP(5);  // scanning
+#if defined(NGD_EMT_STAMPS)
+      if (t0 == 0) EMT_STAMP(5); else EMT_STAMP(7);  // scanning: a site's first round / its later rounds
+#endif
       const bool left = __builtin_amdgcn_ballot_w64(todo != 0) != 0;
       if (left && lane == 0) L.more[round & 1] = 1;
       wg_barrier();  // also the barrier that lets the next round overwrite the tables
@@ -507,9 +564,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 
 }  // namespace
 
-// shape: 0 = 8 wavefronts x 8 rows, 16 steps per round, 4 waves per SIMD (default: [measured] 1000 x 2e4, ms per launch:
-//            49.4; shape 1: 59.6; 2: 51.9; 3: 51.3; k_accum_em<fast> 122.7);
-//        1 = 4 wavefronts x 16 rows, 16 steps, 2 waves per SIMD (register-rich);  2 / 3 = the same two with 12 steps
+// shape: 0 = 8 wavefronts x 8 rows, 16 steps per round, 4 waves per SIMD, a site's later rounds in packed units
+//            (default: [measured] 1000 x 2e4, ms per launch: 46.0; shape 4, the same with every round scanned row by
+//            row: 49.2 -- same bits; shape 1: 59.6; 2: 51.9; 3: 51.3; k_accum_em<fast> 122.7);
+//        1 = 4 wavefronts x 16 rows, 16 steps, 2 waves per SIMD (register-rich);  2 / 3 = 0's and 1's shapes with 12
+//            steps per round, rows only
 void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
                                const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
@@ -525,11 +584,11 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
     else   { if (p) NGD_EMT(NW, CH, WPS, false, true, K); else NGD_EMT(NW, CH, WPS, false, false, K); } \
   } while (0)
   switch (shape) {
-    default: NGD_EMT_WP(8, 16, 4, false); break;
+    default: NGD_EMT_WP(8, 16, 4, true); break;
     case 1: NGD_EMT_WP(4, 16, 2, false); break;
     case 2: NGD_EMT_WP(8, 12, 4, false); break;
     case 3: NGD_EMT_WP(4, 12, 2, false); break;
-    case 4: NGD_EMT_WP(8, 16, 4, true); break;
+    case 4: NGD_EMT_WP(8, 16, 4, false); break;
   }
 #undef NGD_EMT_WP
 #undef NGD_EMT

@@ -624,7 +624,7 @@ def test_random_shapes_flags_and_plans():
         n_rep = int(rng.choice([0, 1, 2, 17]))
         partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
         geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8])), exact_shapes=int(rng.integers(0, 3)) if kernel == "mfma" else 0,
-                    variant=int(rng.integers(0, 4)) if kernel == "em_table" else 0)
+                    variant=int(rng.integers(0, 5)) if kernel == "em_table" else 0)
         score = O.score_matrix(bool(rng.integers(0, 2)))
         p = O.synth_indmajor(100 + case, n_ind, n_sites, miss_frac=miss)
         n_eff = n_sites - n_sites % B

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ngsdist_amd as N  # noqa: E402
 
 n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-variants = [int(v) for v in sys.argv[2:]] or [0, 4]
+variants = [int(v) for v in sys.argv[2:]] or [4, 0]
 n_ind = 1000
 ref = {}
 for case, kw, fill in (("plain", {}, 0.0), ("pairwise_del, 10% missing", {"pairwise_del": True}, 0.1)):

@@ -12,9 +12,9 @@ import ngsdist_amd as N  # noqa: E402
 n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 shape = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_ind = 1000
-nw = 8 if shape in (0, 2) else 4
+nw = 8 if shape in (0, 2, 4) else 4
 rpw = 64 // nw
-names = ["loop", "wait GL loads", "site set-up", "build", "barrier 1", "scan", "barrier 2", "-"]
+names = ["loop", "wait GL loads", "site set-up", "build", "barrier 1", "scan round 1", "barrier 2", "scan later rounds"]
 with N.Engine(n_ind, n_sites, indep_geno=False, kernel="em_table", variant=shape) as e:
     e.synth_fill(3)
     s, c = e.run()
@@ -25,5 +25,5 @@ tot = np.zeros(8)
 for w in range(nw):
     v = np.array([s[idx(w * rpw + r, 64)] if r < rpw else 0.0 for r in range(8)])
     tot += v
-    print("wave %d: " % w + "  ".join("%s %.3g" % (names[k], v[k]) for k in range(7)) + "  | sum %.3g" % v.sum())
-print("share:  " + "  ".join("%s %.1f%%" % (names[k], 100 * tot[k] / tot.sum()) for k in range(7)))
+    print("wave %d: " % w + "  ".join("%s %.3g" % (names[k], v[k]) for k in range(8)) + "  | sum %.3g" % v.sum())
+print("share:  " + "  ".join("%s %.1f%%" % (names[k], 100 * tot[k] / tot.sum()) for k in range(8)))

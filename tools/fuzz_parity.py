@@ -31,7 +31,7 @@ for case in range(first, first + n_cases):
     n_rep = int(rng.choice([0, 1, 2, 3, 5, 17, 33]))
     partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 3)) if kernel == "mfma" else 0,
-                variant=int(rng.integers(0, 4)) if kernel == "em_table" else 0)
+                variant=int(rng.integers(0, 5)) if kernel == "em_table" else 0)
     score = O.score_matrix(bool(rng.integers(0, 2)))
     model = int(rng.integers(0, 3))
     p = O.synth_indmajor(1000 + case, n_ind, n_sites, miss_frac=miss)
