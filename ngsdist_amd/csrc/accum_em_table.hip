@@ -411,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     double g[3] = {gn[0], gn[1], gn[2]};
 #if defined(NGD_EMT_STAMPS)
     asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]));  // the wait for the loads happens here
-    EMT_STAMP(1);  // waiting for this site's likelihoods
+    EMT_STAMP(0);  // waiting for this site's likelihoods (counted with the loop overhead)
 #endif
     if (si + 1 < n_mine) load_site(s + 1, gn);  // in flight while this site is worked on
     if (WEIGHTED) {
@@ -545,7 +545,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       const bool left = __builtin_amdgcn_ballot_w64(todo != 0) != 0;
       if (left && lane == 0) L.more[round & 1] = 1;
       wg_barrier();  // also the barrier that lets the next round overwrite the tables
-      EMT_STAMP(6);  // barrier after scanning
+#if defined(NGD_EMT_STAMPS)
+      if (t0 == 0) EMT_STAMP(6); else EMT_STAMP(1);  // barrier after scanning: first round / later rounds
+#endif
       if (*(const volatile __attribute__((address_space(3))) uint32_t *)&L.more[round & 1] == 0) { round++; break; }
     }
   }

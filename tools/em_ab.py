@@ -28,5 +28,7 @@ for case, kw, fill in (("plain", {}, 0.0), ("pairwise_del, 10% missing", {"pairw
         if key not in ref:
             ref[key] = (s, c, sb, cb)
         same = all(np.array_equal(a, b) for a, b in zip(ref[key], (s, c, sb, cb)))
-        print("%-28s variant %d: %.2f ms per launch (min of %s), rounds per (tile, site) %.3f, bits equal to variant %d: %s"
-              % (case, v, min(ms), " ".join("%.1f" % x for x in ms), r[1] / max(1, r[0]), variants[0], same), flush=True)
+        rel = max(float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) for a, b in ((s, ref[key][0]), (sb, ref[key][2])))
+        print("%-28s variant %d: %.2f ms per launch (min of %s), rounds per (tile, site) %.3f, vs variant %d: bits equal %s, "
+              "max rel diff %.2e, counts equal %s" % (case, v, min(ms), " ".join("%.1f" % x for x in ms), r[1] / max(1, r[0]),
+                                                     variants[0], same, rel, np.array_equal(c, ref[key][1])), flush=True)

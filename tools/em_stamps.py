@@ -14,7 +14,7 @@ shape = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_ind = 1000
 nw = 8 if shape in (0, 2, 4) else 4
 rpw = 64 // nw
-names = ["loop", "wait GL loads", "site set-up", "build", "barrier 1", "scan round 1", "barrier 2", "scan later rounds"]
+names = ["loop + wait GL loads", "barrier 2 later rounds", "site set-up", "build", "barrier 1", "scan round 1", "barrier 2 round 1", "scan later rounds"]
 with N.Engine(n_ind, n_sites, indep_geno=False, kernel="em_table", variant=shape) as e:
     e.synth_fill(3)
     s, c = e.run()
