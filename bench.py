@@ -38,9 +38,7 @@ BYTES_PER_PAIR_SITE = 48.0  # stream model: two 3-double GL vectors per pair-sit
 FLOPS_PER_PAIR_SITE = 6.0   # tiled model: 3 FP64 FMA per pair-site (P . Q^T, K = 3*n_sites)
 PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (SURVEY 8d hardware constants)
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-# EM path, VALU lane-instructions counted in the ISA of the shipped kernels
-EMT_OPS_PER_SITE = 5.4      # k_accum_em_table: per-site set-up, per pair
-EMT_OPS_PER_ROUND = 65.6    # ... per pair and table round of 16 EM steps (scan + finalise 52.6, table build 13.0)
+# EM path: the per-pair algorithm's work (round 1's kernel), for comparison with what the table kernel executes
 EMFAST_OPS_PER_PAIR_SITE = 272.0  # k_accum_em<fast>: SQ_THREAD_CYCLES_VALU per pair-site, profiles/r01_cfg4_em_pmc.md
 
 WORKLOADS = {
@@ -399,20 +397,28 @@ def main():
                    "sample": "first %d of %d sites, all %d pairs, same generator/seed; rate scaled linearly "
                              "in n_sites to one full matrix" % (cs, n_sites, n_pairs)}
             if not W["indep"]:
-                # the reference's OWN em2() (oracle/_ref/libref_em2.so = emOptim2.cpp compiled as it lies), one
-                # thread, on pair-sites of this workload: the per-(pair, site) cost of the reference's EM branch
+                # The same threaded pair loop on the reference's OWN em2() (oracle/_ref/libref_em2.so = emOptim2.cpp
+                # compiled from the reference tree as it lies, no stand-ins), all host cores, on the first part of the
+                # same sample; its sums must carry the bits of the restatement's.
                 try:
-                    R = O.ref_lib()
-                    m = 1_000_000
-                    pa = np.ascontiguousarray(O.synth_indmajor(W["seed"], n_ind, m, i0=0, n_sub=1)[0])
-                    pb = np.ascontiguousarray(O.synth_indmajor(W["seed"], n_ind, m, i0=1, n_sub=1)[0])
-                    sfs = np.empty((m, 9))
-                    tr = time.perf_counter()
-                    R.ref_em2_batch(m, O._dp(pa), O._dp(pb), O._dp(sfs))
-                    tr = time.perf_counter() - tr
-                    cpu["reference_em2"] = {"pair_sites_per_s": m / tr, "cores": 1, "kind": "reference",
-                                            "sample": "em2() of the reference's emOptim2.cpp on the first %d sites of "
-                                                      "pair (0,1); excludes gen_dist's loop around it" % m}
+                    if not O.use_reference_em2(True):
+                        raise RuntimeError("oracle/_ref/libref_em2.so not built")
+                    try:
+                        cr = max(32, cs // 3)
+                        pr = np.ascontiguousarray(pc[:, :cr])
+                        tr = time.perf_counter()
+                        sr, _ = O.all_pairs(pr, indep_geno=False, n_threads=cores)
+                        tr = time.perf_counter() - tr
+                    finally:
+                        O.use_reference_em2(False)
+                    sp, _ = O.all_pairs(pr, indep_geno=False, n_threads=cores)
+                    ref_ps = n_pairs * cr / tr
+                    cpu["reference_em2"] = {
+                        "value": ref_ps / n_sites, "unit": "pair-distances/s", "cores": cores, "kind": "reference-em2",
+                        "pair_sites_per_s": ref_ps, "seconds": tr, "bit_identical_to_port": bool(np.array_equal(sr, sp)),
+                        "sample": "first %d of %d sites, all %d pairs: gen_dist's loop as restated in oracle/, em2() the "
+                                  "reference's own (emOptim2.cpp:112-135); rate scaled linearly in n_sites"
+                                  % (cr, n_sites, n_pairs)}
                 except Exception as exc:
                     cpu["reference_em2"] = {"error": repr(exc)}
     except Exception as exc:  # reported in the line, which is then marked invalid (exit code 1)
@@ -444,28 +450,46 @@ def main():
         # the ISA: the data-dependent factor is the number of EM steps, which the table kernel
         # reports as table rounds per (tile, site) and which is fixed at its measured mean for the per-pair kernels.
         ps_launch = pair_sites_per_launch_all / world
+        lane_peak = PEAK_FP64_TFLOPS * 1e12 / 2  # FP64 lane-instruction slots per second (1 slot = 1 FMA = 2 flop)
+        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
+                "pair_sites_per_s": ps_launch / t_acc,
+                "algorithmic": "FP64 vector pipe (shares the FP64 MFMA datapath and its 78.6 TFLOP/s); 1 lane-instruction "
+                               "= 1 FMA slot = 2 flop"}
+        # Work per pair-site of THIS kernel on THIS data, from the PMC pass of tools/em_pmc.sh (accepted only if it was
+        # measured on the kernel source this library was built from): lanes that executed a VALU instruction
+        # (SQ_THREAD_CYCLES_VALU) and issue slots taken (SQ_INSTS_VALU x 64).  `frac` is the ACTIVE-LANE figure: it cannot
+        # be raised by issuing instructions whose lanes are masked off; the issue-slot figure is reported beside it.
+        try:
+            import hashlib
+            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_%s_%s.json" % (args.workload, kernel))))
+            src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
+            now = hashlib.sha256(open(os.path.join(ROOT, "ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+            stale = vj.get("kernel_source_sha16", {}).get(src) != now
+            act, iss = vj["per_pair_site"]["active_lane_instructions"], vj["per_pair_site"]["issue_slots"]
+            roof["achieved"] = act * ps_launch / t_acc * 2 / 1e12
+            roof["frac"] = roof["active_lane_frac"] = act * ps_launch / t_acc / lane_peak
+            roof["issue_slot_frac"] = iss * ps_launch / t_acc / lane_peak
+            roof["frac_kind"] = ("active lanes: %.1f executed lane-instructions per pair-site (SQ_THREAD_CYCLES_VALU) x pair-sites "
+                                 "/ launch time / %.3g slots per second; issue_slot_frac prices the %.1f slots the kernel "
+                                 "ISSUES per pair-site (SQ_INSTS_VALU x 64), masked lanes included" % (act, lane_peak, iss))
+            roof["valu_source"] = "profiles/valu_%s_%s.json (%s)" % (args.workload, kernel, vj.get("source"))
+            if stale:
+                roof["valu_stale"] = "measured on another version of %s" % src
+        except Exception as exc:
+            roof["frac_kind"] = "no PMC pass of this kernel under profiles/ (%r)" % (exc,)
         if kernel == "em_table":
             tile_sites, rounds = eng.em_work()
-            rounds_per_site = rounds / max(1, tile_sites)
-            ops = EMT_OPS_PER_SITE + rounds_per_site * EMT_OPS_PER_ROUND
-            how = ("%.1f + %.3f table rounds per (tile, site) x %.1f VALU lane-instructions per pair-site (ISA count of "
-                   "k_accum_em_table: scan 52.6 + table build 13.0 per pair and round, 5.4 per site)"
-                   % (EMT_OPS_PER_SITE, rounds_per_site, EMT_OPS_PER_ROUND))
-        elif kernel == "em_fast":
-            ops, how = EMFAST_OPS_PER_PAIR_SITE, ("%.0f VALU lane-instructions per pair-site (k_accum_em<fast> at the mean "
-                                                  "11.7 EM steps of this data set, profiles/r01_cfg4_em_pmc.md)"
-                                                  % EMFAST_OPS_PER_PAIR_SITE)
-        else:
-            ops, how = None, "bit-faithful form: divides and log per step; no operation count kept"
-        ach = ops * ps_launch / t_acc * 2 / 1e12 if ops else None
-        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": ach, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_TFLOPS if ach else None, "traffic": None,
-                "ms_per_launch": acc_mean_ms, "pair_sites_per_s": ps_launch / t_acc,
-                "algorithmic": "FP64 vector issue (shares the FP64 MFMA datapath and its 78.6 TFLOP/s); 1 lane-instruction "
-                               "= 1 FMA slot = 2 flop; " + how}
-        if ops:  # the same launch priced with the per-pair algorithm's count (round 1's kernel): > 1 means work removed
-            roof["per_pair_model"] = {"lane_instructions_per_pair_site": EMFAST_OPS_PER_PAIR_SITE,
-                                      "frac": EMFAST_OPS_PER_PAIR_SITE * ps_launch / t_acc * 2 / 1e12 / PEAK_FP64_TFLOPS}
+            roof["table_rounds_per_tile_site"] = rounds / max(1, tile_sites)
+        # SURVEY 8(d)'s algorithmic count of the reference's form (emOptim2.cpp:77-109: per EM step 36 mul + 37 add + 18 div
+        # + 1 log, + the first lik2 and the 18-flop scoring per site), at this data set's mean of 11.7 steps per pair-site
+        ref_flop = 11.7 * (36 + 37 + 18 + 1) + (27 + 1) + 18
+        roof["reference_form_model"] = {"flop_per_pair_site": ref_flop, "achieved_TFLOPs": ref_flop * ps_launch / t_acc / 1e12,
+                                        "note": "what the reference's arithmetic would need at this rate; the kernel's closed "
+                                                "form and per-individual tables remove most of it (DESIGN.md section 3, K2)"}
+        # the same launch priced with the per-pair algorithm's count (round 1's kernel): > 1 means work removed
+        roof["per_pair_model"] = {"lane_instructions_per_pair_site": EMFAST_OPS_PER_PAIR_SITE,
+                                  "frac": EMFAST_OPS_PER_PAIR_SITE * ps_launch / t_acc / lane_peak}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the one
     # the last tools/profile.sh run of this same command left in profiles/ -- accepted only if the kernel source it was

@@ -264,6 +264,13 @@ int ngo_em2(double *sfs, const double *g1, const double *g2, double tole,
   return it;
 }
 
+/* Optional: run the pair loop below on ANOTHER em2 with this signature -- oracle/_ref's ref_em2_tls, i.e. the
+ * reference's own emOptim2.cpp compiled from where it lies -- so that the threaded CPU baseline can be timed on the
+ * reference's code for the EM (bench.py, "reference-em2").  NULL (default) = the restatement above. */
+typedef int (*ngo_em2_fn)(double *, const double *, const double *, double, int);
+static ngo_em2_fn ngo_em2_hook = 0;
+void ngo_set_em2_hook(ngo_em2_fn fn) { ngo_em2_hook = fn; }
+
 /* ------------------------------------------------------------------------ */
 /* gen_dist: ngsDist.cpp:325-404                                             */
 /* ------------------------------------------------------------------------ */
@@ -293,7 +300,7 @@ void ngo_pair_accum(const double *p, uint64_t n_sites_total,
     if (pairwise_del && (ngo_miss_data(g1) || ngo_miss_data(g2))) continue;
     double sfs[9];
     for (int k = 0; k < 9; k++) sfs[k] = (double)1 / 9; /* ngsDist.cpp:340 */
-    if (!indep_geno) iters += (uint64_t)ngo_em2(sfs, g1, g2, 0.001, 50);
+    if (!indep_geno) iters += (uint64_t)(ngo_em2_hook ? ngo_em2_hook(sfs, g1, g2, 0.001, 50) : ngo_em2(sfs, g1, g2, 0.001, 50));
     for (int a = 0; a < 3; a++)
       for (int b = 0; b < 3; b++)
         dist += score[3 * a + b] * (indep_geno ? g1[a] * g2[b] : sfs[3 * a + b]);

@@ -88,6 +88,21 @@ def ref_lib():
     return _REF
 
 
+def use_reference_em2(on):
+    """all_pairs(indep_geno=False) on the reference's own em2() (oracle/_ref, emOptim2.cpp as it lies) instead of the
+    restated one; returns False if oracle/_ref was never built.  Process-wide; switch it back off after use."""
+    L = lib()
+    L.ngo_set_em2_hook.argtypes = [C.c_void_p]
+    if not on:
+        L.ngo_set_em2_hook(None)
+        return True
+    R = ref_lib()
+    if R is None or not hasattr(R, "ref_em2_tls"):
+        return False
+    L.ngo_set_em2_hook(C.cast(R.ref_em2_tls, C.c_void_p))
+    return True
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

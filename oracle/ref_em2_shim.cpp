@@ -31,6 +31,21 @@ extern "C" void ref_em2(double *sfs, const double *gl1, const double *gl2,
   dalloc(GL2, 1);
 }
 
+/* the same call with the two 1x3 operands allocated once per thread, as gen_dist() allocates them once per pair
+ * (ngsDist.cpp:329-330) and not per site: what the oracle's threaded pair loop calls when it is asked to run the
+ * reference's own em2() (ngo_set_em2_hook) */
+extern "C" int ref_em2_tls(double *sfs, const double *gl1, const double *gl2,
+                           double tole, int max_iter) {
+  static thread_local Matrix<double> GL1 = alloc(1, 3);
+  static thread_local Matrix<double> GL2 = alloc(1, 3);
+  for (int g = 0; g < 3; g++) {
+    GL1.mat[0][g] = gl1[g];
+    GL2.mat[0][g] = gl2[g];
+  }
+  em2(sfs, &GL1, &GL2, tole, max_iter, 9);
+  return 0;
+}
+
 /* many sites at once: sfs_out[n][9], gl1[n][3], gl2[n][3]; start = 1/9 as in
  * ngsDist.cpp:340 */
 extern "C" void ref_em2_batch(size_t n, const double *gl1, const double *gl2,

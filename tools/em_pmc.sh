@@ -43,4 +43,14 @@ if "SQ_INSTS_LDS" in m:
 print("- wave-cycles: WAIT_ANY %.1f%%, WAIT_INST_ANY %.1f%% of SQ_WAVE_CYCLES; waves per launch %.4g" % (
     100 * m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"], 100 * m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], m.get("SQ_WAVES", 0)))
 print("- %.3g pair-sites/s" % (ps / (ms * 1e-3)))
+# what bench.py's EM roofline reads (profiles/valu_cfg4_<kernel>.json): work per pair-site, tied to the kernel source
+import hashlib, os
+src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
+sha = hashlib.sha256(open(os.path.join("ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+json.dump({"source": "tools/em_pmc.sh %s %g (rocprofv3 --pmc, two passes)" % (kernel, ns), "kernel_source_sha16": {src: sha},
+           "per_pair_site": {"active_lane_instructions": m["SQ_THREAD_CYCLES_VALU"] / ps, "issue_slots": m["SQ_INSTS_VALU"] * 64 / ps,
+                             "lds_wave_instructions": m.get("SQ_INSTS_LDS", 0) / ps},
+           "lane_occupancy": m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"] / 64,
+           "lds_busy": m.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc), "shader_mhz": cyc / ms / 1e3},
+          open(out + "/valu_cfg4_%s.json" % kernel, "w"), indent=1)
 PY
