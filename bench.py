@@ -89,6 +89,9 @@ def main():
                     help="--pairwise_del with --miss_frac missing sites: counts differ per pair, so the N>1 flow also "
                          "reduce-scatters the valid-site counts (not a BASELINE configuration)")
     ap.add_argument("--miss_frac", type=float, default=0.0, help="fraction of exact (1/3,1/3,1/3) sites in the input")
+    ap.add_argument("--serial_tail", action="store_true",
+                    help="N=1: finish a job's host tail (copy out, /cnt, evolutionary model) before the next job's kernels "
+                         "start, instead of running it beside them (the default): ms_per_step is then ONE job's latency")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -196,10 +199,10 @@ def main():
         total = n_mat * n_pairs
         chunk, c_lo, c_hi = share_of(total, rank, world)
         d_flat = torch.zeros(world * chunk, dtype=torch.float64, device=dev)  # the engine's (partial) sums
-        d_all = d_flat[:total].view(n_mat, n_pairs)
+        d_all_1 = d_flat[:total].view(n_mat, n_pairs)
         # the engine's valid-site counts (ngsDist.cpp:362): per rank its own sites' / its own pairs' share
         d_cflat = torch.zeros(world * chunk, dtype=torch.int64, device=dev)
-        d_call = d_cflat[:total].view(n_mat, n_pairs)
+        d_call_1 = d_cflat[:total].view(n_mat, n_pairs)
         # without --pairwise_del a cell's count is the number of sites its matrix visits: no exchange needed
         cnt_flat = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
         cnt_flat[0, :] = n_sites
@@ -219,12 +222,21 @@ def main():
             h_dist_all = pin(world * chunk)
             h_flat = pin(world * chunk) if not on_gpu else None
         else:
-            h_all = pin(n_mat, n_pairs)
+            # N = 1: jobs are pipelined two deep -- while the host copies job k out and runs its tail (worker thread:
+            # ngd_finish on the host's libm), the GPU accumulates job k+1 into the other set of buffers
+            import concurrent.futures
+            tail_pool = concurrent.futures.ThreadPoolExecutor(1)
+            tail_job = [None, None]
+            step_no = [0]
+            d_flat_b = [d_flat, torch.zeros_like(d_flat)]
+            d_cflat_b = [d_cflat, torch.zeros_like(d_cflat)]
+            h_all_b = [pin(n_mat, n_pairs), pin(n_mat, n_pairs)]
+            h_call_b = [h_call, torch.empty(total, dtype=torch.int64).pin_memory()] if pdel else [None, None]
             dist_all = np.zeros((n_mat, n_pairs))
             copy_stream = torch.cuda.Stream()
             step_m = max(1, n_mat // 8)
             chunks = [(a, min(n_mat, a + step_m)) for a in range(0, n_mat, step_m)]
-            chunk_ev = [torch.cuda.Event() for _ in chunks]
+            chunk_ev = [[torch.cuda.Event() for _ in chunks] for _ in range(2)]
     if batched:
         n_blocks = n_eff // W["block"]
         fold0 = n_eff == n_sites
@@ -259,35 +271,51 @@ def main():
             last["dist"] = h_all[-1].numpy()
             return
         # the job's (partial) sums, every matrix: one engine call per plan
+        if world == 1:
+            buf = step_no[0] & 1
+            step_no[0] += 1
+            if tail_job[buf] is not None:  # the job that used this set of buffers two steps ago has left them
+                tail_job[buf].result()
+            da, dc = d_flat_b[buf][:total].view(n_mat, n_pairs), d_cflat_b[buf][:total].view(n_mat, n_pairs)
+        else:
+            da, dc = d_all_1, d_call_1
         if batched:
             first = 0 if fold0 else 1
             if not fold0:
-                eng.run_device(d_all[0].data_ptr(), d_call[0].data_ptr())
+                eng.run_device(da[0].data_ptr(), dc[0].data_ptr())
                 if record:
                     record_timing()
-            eng.run_batch(mult=mult_all, block_size=W["block"], d_sum_ptr=d_all[first].data_ptr(),
-                          d_cnt_ptr=d_call[first].data_ptr())
+            eng.run_batch(mult=mult_all, block_size=W["block"], d_sum_ptr=da[first].data_ptr(),
+                          d_cnt_ptr=dc[first].data_ptr())
         else:
-            eng.run_device(d_all[0].data_ptr(), d_call[0].data_ptr())
+            eng.run_device(da[0].data_ptr(), dc[0].data_ptr())
         if record:
             record_timing()
         if world == 1:
-            # results leave the device in chunks of matrices; the host tail (ngd_finish) of one chunk runs while
-            # the next is in flight
-            copy_stream.wait_stream(torch.cuda.current_stream())
+            # results leave the device in chunks of matrices (the engine call has synchronised its stream); the host
+            # tail (ngd_finish) of one chunk runs while the next is in flight -- on the worker thread, so that this
+            # thread can hand the GPU the next job meanwhile
+            ha, h_call1, evs = h_all_b[buf], h_call_b[buf], chunk_ev[buf]
             with torch.cuda.stream(copy_stream):
                 if pdel:
-                    h_call.copy_(d_cflat[:total], non_blocking=True)
+                    h_call1.copy_(d_cflat_b[buf][:total], non_blocking=True)
                 for c, (a, b) in enumerate(chunks):
-                    h_all[a:b].copy_(d_all[a:b], non_blocking=True)
-                    chunk_ev[c].record(copy_stream)
-            cnts = h_call.numpy().view(np.uint64) if pdel else cnt_flat
-            with np.errstate(all="ignore"):
-                for c, (a, b) in enumerate(chunks):
-                    chunk_ev[c].synchronize()
-                    N.finish(h_all[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], 0, W["evol_model"],
-                             out=dist_all[a:b].reshape(-1))
-            last["dist"] = dist_all[-1]
+                    ha[a:b].copy_(da[a:b], non_blocking=True)
+                    evs[c].record(copy_stream)
+
+            def tail():
+                cnts = h_call1.numpy().view(np.uint64) if pdel else cnt_flat
+                with np.errstate(all="ignore"):
+                    for c, (a, b) in enumerate(chunks):
+                        evs[c].synchronize()
+                        N.finish(ha[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], 0, W["evol_model"],
+                                 out=dist_all[a:b].reshape(-1))
+                last["dist"] = dist_all[-1]
+
+            if args.serial_tail:
+                tail()
+            else:
+                tail_job[buf] = tail_pool.submit(tail)
             return
         # N > 1: reduce-scatter (partial sums add / disjoint shards meet) -> every rank finishes its share of the
         # cells on its own host cores -> all-gather of the finished cells
@@ -322,6 +350,10 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
+        elif not by_reps:
+            for j in tail_job:  # every job handed in so far is finished, host tail included
+                if j is not None:
+                    j.result()
         torch.cuda.synchronize()
 
     def allred(x, op):
@@ -522,6 +554,10 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
+                   "host_tail": ("serial: a job's copy-out and ngd_finish end before the next job's kernels start "
+                                 "(ms_per_step = one job's latency)" if args.serial_tail or world > 1 or by_reps else
+                                 "pipelined: job k's copy-out and ngd_finish (worker thread) run beside job k+1's kernels; "
+                                 "all K jobs, tails included, end inside the timed region"),
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "
                                 "reduce-scatter adds the sums, every rank finishes its 1/%d of the cells on its host, one "
