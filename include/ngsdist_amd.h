@@ -55,7 +55,8 @@ typedef struct ngd_engine ngd_engine;
 /* The subset of the reference's `params` (ngsDist.hpp:11-44) that gen_dist()
  * reads, plus placement. */
 typedef struct ngd_config {
-  uint64_t n_ind;       /* params.n_ind                                       */
+  uint64_t n_ind;       /* params.n_ind; bounded by device memory (NGD_E_NOMEM: two n_pairs-long result arrays +  */
+                        /* n_pad^2 doubles per slice), never above 1 048 448 (16-bit tile indices)          */
   uint64_t n_sites;     /* params.n_sites of the loaded data set              */
   double score[9];      /* params.score[g1][g2] row-major, parse_args.cpp:25-27,134-137 */
   int32_t pairwise_del; /* params.pairwise_del, ngsDist.cpp:335-338           */
@@ -67,7 +68,8 @@ typedef struct ngd_config {
   /* Launch geometry; 0 = the measured defaults, which is what a host wants.  They change
    * speed only, never results beyond the order of additions over site slices. */
   uint32_t variant;      /* NGD_KERNEL_EM_TABLE: workgroup shape 0..4 (accum_em_table.hip)            */
-  uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8)  */
+  uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8);  */
+                         /* held to what the data set allows (>= 128 k-groups / >= 1 site per slice)  */
   uint32_t wg_target;    /* workgroups wanted per launch, from which n_slices is derived when it is 0 */
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 = always issue only the MFMA tiles a block   */
                          /* needs (auto: when n_ind padded to 128 is at most 384)                      */

@@ -186,7 +186,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   *out = nullptr;
   if (cfg->n_ind < 2) return fail(NGD_E_INVALID, "ngd_create: need at least 2 individuals");
   if (cfg->n_sites < 1) return fail(NGD_E_INVALID, "ngd_create: need at least 1 site");
-  if (cfg->n_ind > 60000) return fail(NGD_E_INVALID, "ngd_create: n_ind > 60000 not supported");
+  // tile lists index groups of 16 individuals with 16 bits; what bounds n_ind in practice is device memory (two
+  // n_pairs-long result arrays + one n_pad x n_pad plane per slice), checked below before any list is built
+  if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
   if (cfg->exact_shapes > 2) return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never) or 2 (always)");
@@ -201,6 +203,13 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (dev < 0) HIPCHK(hipGetDevice(&dev));
   if (dev >= n_dev) return fail(NGD_E_NODEVICE, "ngd_create: device ordinal out of range");
   HIPCHK(hipSetDevice(dev));
+  {
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t n_pad = (cfg->n_ind + 127) / 128 * 128;
+    const uint64_t least = ngd_n_pairs(cfg->n_ind) * 16 + 8 * n_pad * n_pad * 8;  // results + the fewest slab planes
+    if (least > total_b) return fail(NGD_E_NOMEM, "ngd_create: the result arrays of this many individuals exceed the device's memory");
+  }
 
   int kernel = cfg->kernel;
   if (cfg->indep_geno) {
@@ -414,7 +423,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       }
       ks = best_ks;
     }
-    if (cfg->n_slices) ks = cfg->n_slices;
+    if (cfg->n_slices) ks = std::min<uint64_t>(cfg->n_slices, max_ks);  // a caller's count is held to the same bound
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
@@ -427,7 +436,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     uint64_t ks = e->n_tiles64 ? (want + e->n_tiles64 - 1) / e->n_tiles64 : 1;
     uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 64);
     ks = std::min(ks, max_ks);
-    if (cfg->n_slices) ks = cfg->n_slices;
+    if (cfg->n_slices) ks = std::min<uint64_t>(cfg->n_slices, g.n_sites);  // never more slices than sites
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
@@ -437,7 +446,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
     uint64_t max_ks = std::max<uint64_t>(1, g.n_sites / 256);
     ks = std::min(ks, max_ks);
-    if (cfg->n_slices) ks = cfg->n_slices;
+    if (cfg->n_slices) ks = std::min<uint64_t>(cfg->n_slices, g.n_sites);  // never more slices than sites
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));

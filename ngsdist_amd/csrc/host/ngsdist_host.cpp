@@ -1049,6 +1049,10 @@ int main(int argc, char **argv) {
     const uint64_t n_eff = p.n_boot_rep ? p.n_sites - p.n_sites % B : 0, n_blocks = p.n_boot_rep ? n_eff / B : 0;
     uint64_t unit = 16;  // ranges are whole 16-site groups and whole bootstrap blocks
     if (p.n_boot_rep) { uint64_t a = 16, b = B; while (b) { uint64_t t = a % b; a = b; b = t; } unit = 16 / a * B; }
+    // lcm(16, B) can exceed the data set (a large odd block size): then no split into whole units exists, one range
+    // is the whole data set, and it only has to fit one device
+    const uint64_t whole = (p.n_sites + 15) / 16 * 16;
+    if (unit > whole) unit = whole;
     if (budget <= fixed || (budget - fixed) / per_site < unit)
       die(__FUNCTION__, "not even one range of sites (16 sites / one bootstrap block) fits the device");
     const uint64_t cap = (budget - fixed) / per_site / unit * unit;  // sites one device holds
@@ -1112,7 +1116,10 @@ int main(int argc, char **argv) {
     Loader L(p);
     if (L.seekable() && G > 1) {
       // plain binary file: every device's thread reads its own ranges (nothing is read twice, nothing is replicated)
-      L.finish(p.n_sites * p.n_ind * 24 != L.raw_size);  // the size check of the whole file, once
+      // the size check of the whole file, once, with the reference's two messages (read_data.cpp:45-47, :106-109)
+      if (L.raw_size < p.n_sites * p.n_ind * 24)
+        die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+      L.finish(p.n_sites * p.n_ind * 24 != L.raw_size);
       std::vector<std::thread> th;
       for (uint64_t d = 0; d < G; d++)
         th.emplace_back([&, d]() {

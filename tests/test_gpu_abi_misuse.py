@@ -41,7 +41,7 @@ def test_bad_arguments_are_codes_and_the_engine_survives():
     err(L.ngd_create(C.byref(cfg()), None))
     for bad in (dict(n_ind=1), dict(n_ind=0), dict(n_sites=0), dict(kernel=99), dict(variant=77), dict(exact_shapes=9),
                 dict(shard_rank=3, shard_world=2), dict(n_sites=1 << 40), dict(device=1000), dict(kernel=3, indep_geno=1),
-                dict(kernel=1, indep_geno=0), dict(n_ind=1 << 40, n_sites=1 << 40)):
+                dict(kernel=1, indep_geno=0), dict(n_ind=1 << 40, n_sites=1 << 40), dict(n_ind=500_000, n_sites=64)):
         h = vp()
         err(L.ngd_create(C.byref(cfg(**bad)), C.byref(h)))
         assert not h.value
@@ -99,6 +99,20 @@ def test_bad_arguments_are_codes_and_the_engine_survives():
     assert np.array_equal(c[:n_pairs], co) and np.allclose(s[:n_pairs], so, rtol=1e-12)
     L.ngd_destroy(h)
     L.ngd_destroy(None)  # a no-op, like free(NULL)
+
+
+def test_absurd_launch_geometry_is_held_to_the_data_set():
+    """ngd_config.n_slices / wg_target far beyond the data set: the engine holds them to what the data allows (at
+    least 128 k-groups / one site per slice) instead of allocating a slab per requested slice -- same results"""
+    import ngsdist_amd as N
+    p = O.synth_indmajor(4, 70, 900)
+    for kernel, indep in (("mfma", True), ("em_table", False), ("em_fast", False)):
+        so, co = O.all_pairs(p, indep_geno=indep)
+        for geom in (dict(n_slices=4_000_000_000), dict(wg_target=4_000_000_000), dict(n_slices=1)):
+            with N.Engine(70, 900, indep_geno=indep, kernel=kernel, **geom) as e:
+                s, c = e.upload_ind_major(p).commit().run()
+                assert e.device_bytes() < 1 << 30
+            assert np.array_equal(c, co) and np.max(np.abs(s - so) / np.abs(so)) < 1e-9, (kernel, geom)
 
 
 def test_engines_give_their_device_memory_back():

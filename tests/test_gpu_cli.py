@@ -253,6 +253,17 @@ def test_fewer_sites_than_one_bootstrap_block(tmp_path):
                    "--boot_block_size", 500, "--seed", 1, *extra) == exp
 
 
+def test_block_size_whose_lcm_with_16_exceeds_the_data_set(tmp_path):
+    """--n_gpus ranges are whole multiples of lcm(16, --boot_block_size); a large odd block size makes that exceed
+    n_sites (lcm(16, 67) = 1072 > 200): the job then runs as ONE range on one device instead of dying for want of a
+    device that holds 1072 sites -- same bytes as the one-engine run"""
+    base = ["--geno", T_GL, "--probs", "--n_ind", 6, "--n_sites", 200, "--indep_geno", "--n_boot_rep", 3,
+            "--boot_block_size", 67, "--seed", 5]
+    exp = cli(tmp_path, *base)
+    assert cli(tmp_path, *base, "--n_gpus", 2, "--same_device", name="two.dist") == exp
+    assert cli(tmp_path, *base, "--n_gpus", 2, "--same_device", "--max_device_bytes", 700 << 20, name="cap.dist") == exp
+
+
 def test_bench_line_contract(tmp_path):
     """bench.py prints ONE JSON line with the fields the driver reads."""
     import json
