@@ -181,13 +181,12 @@ int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
  * so a host may draw all maps up front: ngd_boot_block_map n_rep times); mult is [n_rep][n_blocks]
  * (site sharding, as ngd_run_mult).  Outputs are [n_rep][n_pairs].  The engine computes per-block partial
  * (sum, cnt) once and forms up to 32 replicates per pass over them, so a batch costs little more than
- * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run() (one exception:
- * NGD_KERNEL_EM_TABLE with three or more replicates whose blocks are too small for partials borrows the per-pair
- * kernel's batch pass -- those replicates agree with ngd_run()'s to rounding, ~1e-14 relative, not bit for bit).
+ * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run().
  * When the partials do not apply (streaming kernel, not enough device memory for one partial result per
  * block -- e.g. block size 1 on a large data set) this is n_rep weighted accumulation passes on the
- * --indep_geno path (each walks only the sites its replicate drew) and one pass per 16 replicates on the
- * EM path. */
+ * --indep_geno path (each walks only the sites its replicate drew) and, on the EM path, one pass per 8
+ * matrices (table-driven kernel) or 16 (per-pair kernels): the EM of a (pair, site) is computed once and
+ * added to every matrix's accumulator with the site's weight there. */
 int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                   uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,

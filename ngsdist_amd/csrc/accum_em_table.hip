@@ -208,10 +208,14 @@ typedef __attribute__((address_space(3))) const volatile ngd_d2 ngd_lds_cvd2;
 // go out behind this row's six table reads for its terms, so the wait for those leaves them in flight.  QA holds the
 // first-block thresholds: put there by the previous row's call, or read here if `load`.  (Every read is volatile: issue
 // order = program order.)
-template <int CH, bool WEIGHTED, bool PACK>
+// RB matrices at once (the full data set and bootstrap replicates, or replicates only): the pair's term is added to
+// accr[b] with the site's weight wv[b] in matrix b -- product first, then the sum, like the one-matrix kernel, so a
+// matrix carries the same bits from either.
+template <int CH, bool WEIGHTED, bool PACK, int RB>
 __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t rb /* row * RS */, uint32_t rb_next,
                                          uint32_t lane, int r, const double (&R2)[CH], ngd_d2 (&QA)[4], uint32_t &todo,
-                                         double &accr, double wgt, uint32_t skip, bool load, bool pref) {
+                                         double (&accr)[RB], const double (&wv)[RB], uint32_t skip, bool load,
+                                         bool pref) {
   static_assert(CH == 16, "two blocks of eight steps");
   const bool mine = (todo >> r) & 1;
   uint64_t m = __builtin_amdgcn_ballot_w64(mine);
@@ -248,9 +252,9 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
   double c = f0 * g0;
   c = __builtin_fma(f1, g1, c);
   c = __builtin_fma(f2, g2, c);
-  if (WEIGHTED) c = c * wgt;
   if (T) {
-    accr = accr + c;
+#pragma unroll
+    for (int b = 0; b < RB; b++) accr[b] = accr[b] + (WEIGHTED ? c * wv[b] : c);
     todo &= ~(1u << r);
   }
 }
@@ -262,9 +266,9 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
 // address; the search and the term are the plain row's, instruction for instruction (same bits).  The terms then travel
 // inside the wavefront -- through its 512 bytes of unit_c -- to the lanes that own the pairs (lane = column), which
 // add them in the same order as ever: one term per pair and site, 0.0 from the slots that had nothing to add.
-template <int CH, bool WEIGHTED>
+template <int CH, bool WEIGHTED, int RB>
 __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wave, uint32_t lane, uint32_t &todo,
-                                             double (&acc)[8], double wgt) {
+                                             double (&acc)[8][RB], const double (&wv)[RB]) {
   constexpr int RS = em_tables<CH, true>::RS;
   static_assert(CH % 8 == 0, "shape");
   ngd_lds_vd *uc = (ngd_lds_vd *)&L.unit_c[wave * 64];
@@ -302,20 +306,16 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
     double c = lds_b64(&L.Fr[0][a]) * lds_b64(&L.Gc[0][b]);
     c = __builtin_fma(lds_b64(&L.Fr[1][a]), lds_b64(&L.Gc[1][b]), c);
     c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
-    if (WEIGHTED) c = c * wgt;
     const uint64_t done = __builtin_amdgcn_ballot_w64(T != 0);  // bit = 8 * slot + row
-    uc[lane] = T ? c : 0.0;
+    uc[lane] = T ? c : 0.0;  // (unweighted: the owner multiplies; 0 x weight adds nothing)
     if (sel) {  // the owners of this unit's columns collect their 8 rows
       ngd_lds_cvd2 *mail = (ngd_lds_cvd2 *)&L.unit_c[wave * 64 + rank * 8];
       const ngd_d2 v0 = mail[0], v1 = mail[1], v2 = mail[2], v3 = mail[3];
-      acc[0] = acc[0] + v0[0];
-      acc[1] = acc[1] + v0[1];
-      acc[2] = acc[2] + v1[0];
-      acc[3] = acc[3] + v1[1];
-      acc[4] = acc[4] + v2[0];
-      acc[5] = acc[5] + v2[1];
-      acc[6] = acc[6] + v3[0];
-      acc[7] = acc[7] + v3[1];
+      const double v[8] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int b = 0; b < RB; b++) acc[q][b] = acc[q][b] + (WEIGHTED ? v[q] * wv[b] : v[q]);
       todo &= ~((uint32_t)(done >> (rank * 8)) & 0xffu);
     }
     pm &= ~__builtin_amdgcn_ballot_w64(sel);
@@ -342,16 +342,22 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
 // scanned the plain way; the rest goes through packed_units()
 constexpr int PACK_DENSE = 24;
 
-template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK>
+// RB > 1: RB matrices in one pass (bootstrap replicates whose blocks are too small for per-block partial results:
+// the EM of a (pair, site) does not depend on the replicate, only its weight does).  Wb[s][RB] = the site's weight in
+// each matrix; the slab holds RB planes per slice.  The RB x 8 accumulators take the registers of a second workgroup:
+// one workgroup per CU.
+template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK, int RB>
 __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
-    const double *__restrict__ PA, const uint32_t *__restrict__ ws, ngd_score sc, const ngd_tile *__restrict__ tiles,
-    uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind, uint64_t n_sites_eff, uint64_t sites_per_slice,
-    double *__restrict__ slab, unsigned long long *__restrict__ counters) {
+    const double *__restrict__ PA, const uint32_t *__restrict__ ws, const double *__restrict__ Wb, ngd_score sc,
+    const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind,
+    uint64_t n_sites_eff, uint64_t sites_per_slice, double *__restrict__ slab,
+    unsigned long long *__restrict__ counters) {
   constexpr int RPW = TS / NW;  // rows per wavefront
   constexpr int RS = em_tables<CH, PACK>::RS;
-  static_assert(!PACK || (NW == 8 && WPS >= 4), "packed units: 8 wavefronts x 8 rows");
+  static_assert(!PACK || NW == 8, "packed units: 8 wavefronts x 8 rows");
+  static_assert(RB == 1 || (PACK && WEIGHTED), "several matrices per pass: the packed form, weighted");
   // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
-  constexpr int GR = WPS >= 4 ? 1 : 4;
+  constexpr int GR = (WPS >= 4 || PACK) ? 1 : 4;
   static_assert(RPW % GR == 0 && CH % 4 == 0 && (CH % 8 == 0 || CH % 8 == 4), "shape");
   __shared__ em_tables<CH, PACK> L;
   const uint32_t tile = blockIdx.x % n_tiles;
@@ -369,9 +375,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #pragma unroll
   for (int r = 0; r < RPW; r++)
     if (I0 + wave * RPW + r < j && j < n_ind) live |= 1u << r;
-  double acc[RPW];
+  double acc[RPW][RB];
 #pragma unroll
-  for (int r = 0; r < RPW; r++) acc[r] = 0;
+  for (int r = 0; r < RPW; r++)
+#pragma unroll
+    for (int b = 0; b < RB; b++) acc[r][b] = 0;
 
   // building role: every wavefront builds.  Wavefronts 0 .. NW/2-1 own the tile's rows, the others its columns
   // (lane = individual); wavefront p of a role writes steps p*SEG+1 .. (p+1)*SEG of each round, so a round's CH steps
@@ -407,6 +415,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   for (uint32_t si = 0; si < n_mine; si++) {
     const uint64_t s = s0 + si;
     double wgt = 1.0;
+    double wv[RB];
     EMT_STAMP(0);  // loop overhead, end-of-site
     double g[3] = {gn[0], gn[1], gn[2]};
 #if defined(NGD_EMT_STAMPS)
@@ -414,10 +423,20 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     EMT_STAMP(0);  // waiting for this site's likelihoods (counted with the loop overhead)
 #endif
     if (si + 1 < n_mine) load_site(s + 1, gn);  // in flight while this site is worked on
-    if (WEIGHTED) {
+    if (WEIGHTED && RB == 1) {
       const uint32_t m = ws[s];
       if (m == 0) continue;  // site not drawn in this replicate (uniform across the workgroup)
       wgt = (double)m;
+    }
+    wv[0] = wgt;
+    if (RB > 1) {
+      bool any = false;
+#pragma unroll
+      for (int b = 0; b < RB; b++) {
+        wv[b] = Wb[s * RB + b];
+        any = any || wv[b] != 0.0;
+      }
+      if (!any) continue;  // drawn by none of these replicates
     }
     // v = g^(t0 + seg*SEG): the power one step before this wavefront's first step of the round; gch = g^CH
     double v[3] = {1.0, 1.0, 1.0}, gch[3];
@@ -485,11 +504,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #pragma unroll
             for (int r = 0; r < RPW; r++)
               if ((go >> r) & 1)
-                scan_row<CH, WEIGHTED, PACK>(L, (wave * RPW + r) * RS, (wave * RPW + r + 1) * RS, lane, r, R2, QA, todo,
-                                             acc[r], wgt, ((ska >> r) & 1) | (((skb >> r) & 1) << 1), (load >> r) & 1,
-                                             (pref >> r) & 1);
+                scan_row<CH, WEIGHTED, PACK, RB>(L, (wave * RPW + r) * RS, (wave * RPW + r + 1) * RS, lane, r, R2, QA,
+                                                 todo, acc[r], wv, ((ska >> r) & 1) | (((skb >> r) & 1) << 1),
+                                                 (load >> r) & 1, (pref >> r) & 1);
           }
-          if (t0 != 0) packed_units<CH, WEIGHTED>(L, wave, lane, todo, acc, wgt);
+          if (t0 != 0) packed_units<CH, WEIGHTED, RB>(L, wave, lane, todo, acc, wv);
         }
       } else if (__builtin_amdgcn_ballot_w64(todo != 0)) {
         double R2[CH];
@@ -533,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
             c = __builtin_fma(lds_b64(&L.Fr[2][a]), lds_b64(&L.Gc[2][b]), c);
             if (WEIGHTED) c = c * wgt;
             if (T[q]) {
-              acc[r] = acc[r] + c;
+              acc[r][0] = acc[r][0] + c;
               todo &= ~(1u << r);
             }
           }
@@ -557,11 +576,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   }
 #if defined(NGD_EMT_STAMPS)
 #pragma unroll
-  for (int r = 0; r < RPW && r < 8; r++) acc[r] = stamp_sum[r];
+  for (int r = 0; r < RPW && r < 8; r++) acc[r][0] = stamp_sum[r];
 #endif
 #pragma unroll
   for (int r = 0; r < RPW; r++)
-    slab[((uint64_t)ks * n_pad + (I0 + wave * RPW + r)) * n_pad + j] = acc[r];
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+      slab[(((uint64_t)ks * RB + b) * n_pad + (I0 + wave * RPW + r)) * n_pad + j] = acc[r][b];
 }
 
 }  // namespace
@@ -577,9 +598,10 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
                                double *slab, unsigned long long *d_counters) {
   if (!n_tiles64) return;
   const bool w = d_ws != nullptr, p = pairwise_del != 0;
-#define NGD_EMT(NW, CH, WPS, W, P, K)                                                                              \
-  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P, K>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
-                     score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab, d_counters)
+#define NGD_EMT(NW, CH, WPS, W, P, K)                                                                                 \
+  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, W, P, K, 1>), dim3(n_tiles64 * n_ks), dim3(NW * 64), 0, st, PA, d_ws, \
+                     nullptr, score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, slab,  \
+                     d_counters)
 #define NGD_EMT_WP(NW, CH, WPS, K)                                                 \
   do {                                                                             \
     if (w) { if (p) NGD_EMT(NW, CH, WPS, true, true, K); else NGD_EMT(NW, CH, WPS, true, false, K); }   \
@@ -594,4 +616,22 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
   }
 #undef NGD_EMT_WP
 #undef NGD_EMT
+}
+
+// rb (4 or 8) matrices in one pass of the packed form; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
+void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
+                                     uint64_t n_sites_eff, const ngd_score &score, int pairwise_del,
+                                     const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks,
+                                     uint64_t sites_per_slice, double *slab, unsigned long long *d_counters) {
+  if (!n_tiles64) return;
+#define NGD_EMTB(P, RB)                                                                                                  \
+  hipLaunchKernelGGL((k_accum_em_table<8, 16, 2, true, P, true, RB>), dim3(n_tiles64 * n_ks), dim3(512), 0, st, PA,       \
+                     nullptr, d_Wb, score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, n_sites_eff, sites_per_slice, \
+                     slab, d_counters)
+  if (rb == 8) {
+    if (pairwise_del) NGD_EMTB(true, 8); else NGD_EMTB(false, 8);
+  } else {
+    if (pairwise_del) NGD_EMTB(true, 4); else NGD_EMTB(false, 4);
+  }
+#undef NGD_EMTB
 }

@@ -874,11 +874,17 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   const uint64_t n_eff = n_blocks * block_size;
   const uint32_t n_mat = n_rep + (lead_full ? 1u : 0u);
   const bool fast = e->kernel != NGD_KERNEL_EM_FAITHFUL;
-  // slices of the per-pair batch kernel: the engine's own when that is its kernel, else (table-driven engine) what
-  // ngd_create() would have picked for it
+  // the table-driven kernel's own batch form (its default shape): 8 matrices per pass, one workgroup per CU (the 8 x 8
+  // accumulators of a wavefront take the registers of a second one)
+  const bool table = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0;
+  const uint32_t per_pass = table ? 8 : 16;
+  // slices of the per-pair batch kernel: the engine's own when that is its kernel, else (table-driven engine in
+  // another shape) what ngd_create() would have picked for it
   uint32_t b_ks = e->n_ks;
   uint64_t b_per = e->per_slice;
-  if (e->kernel == NGD_KERNEL_EM_TABLE) {
+  if (table) {
+    // the plain pass's own slices: a matrix then adds up in the same order from either (same bits)
+  } else if (e->kernel == NGD_KERNEL_EM_TABLE) {
     uint64_t ks = e->n_tiles16 ? (4096 + e->n_tiles16 - 1) / e->n_tiles16 : 1;
     ks = std::max<uint64_t>(1, std::min(ks, std::max<uint64_t>(1, g.n_sites / 256)));
     b_ks = (uint32_t)ks;
@@ -888,8 +894,8 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   if (e->cfg.shard_world > 1 || e->cfg.pairwise_del)  // k_count adds with integer atomics
     HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_mat * n_pairs * sizeof(unsigned long long), e->st));
   e->boot_B = 0;  // the partial-sum slab is re-used as this pass's scratch
-  for (uint32_t c0 = 0; c0 < n_mat; c0 += 16) {
-    const uint32_t nr = std::min(16u, n_mat - c0);
+  for (uint32_t c0 = 0; c0 < n_mat; c0 += per_pass) {
+    const uint32_t nr = std::min(per_pass, n_mat - c0);
     const int rb = nr <= 4 ? 4 : nr <= 8 ? 8 : 16;
     const bool lead = lead_full && c0 == 0;
     const uint32_t q0 = c0 - ((lead_full && c0 > 0) ? 1u : 0u);  // first replicate of the chunk
@@ -905,8 +911,12 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
     ngd_launch_weights_batch(e->st, e->d_M, nq, (uint32_t)rb, lead ? 1 : 0, n_blocks, block_size, g.n_sites, g.n_sites,
                              e->d_W);
     HIPCHK(hipEventRecord(e->ev[1], e->st));
-    ngd_launch_accum_em_batch(e->st, g, e->PA, e->d_W, rb, lead ? g.n_sites : n_eff, e->sc, e->cfg.pairwise_del, fast,
-                              e->d_tiles16, e->n_tiles16, b_ks, b_per, e->slab_boot);
+    if (table)
+      ngd_launch_accum_em_table_batch(e->st, g, e->PA, e->d_W, rb, lead ? g.n_sites : n_eff, e->sc, e->cfg.pairwise_del,
+                                      e->d_tiles64, e->n_tiles64, b_ks, b_per, e->slab_boot, e->d_emcnt);
+    else
+      ngd_launch_accum_em_batch(e->st, g, e->PA, e->d_W, rb, lead ? g.n_sites : n_eff, e->sc, e->cfg.pairwise_del, fast,
+                                e->d_tiles16, e->n_tiles16, b_ks, b_per, e->slab_boot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e->ev[2], e->st));
     for (uint32_t r = 0; r < nr; r++)
@@ -1013,15 +1023,16 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
     if (rc) return rc;
     if (feasible) return lead ? pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, true) : NGD_OK;
   }
-  // 2. EM kernels: many matrices per accumulation pass (the per-pair kernels' batch form: the EM of a (pair, site) is
-  //    computed once and added to up to 16 accumulators).  The faithful form keeps matrix 0 on the plain pass, whose
-  //    accumulation is the reference's term by term.  The table-driven kernel has no batch form (16 x 8 accumulators do
-  //    not fit its registers); its weighted pass walks only the sites a replicate drew (0.63 of a pass), which is
-  //    cheaper than the per-pair batch pass (2.5 of its own plain passes) up to two replicates -- beyond that the
-  //    table engine borrows the per-pair batch kernel, and those replicates agree with ngd_run()'s to rounding only.
+  // 2. EM kernels: many matrices per accumulation pass (the EM of a (pair, site) is computed once and added to up to
+  //    16 accumulators per pair -- 8 in the table-driven kernel).  The faithful form keeps matrix 0 on the plain pass,
+  //    whose accumulation is the reference's term by term.  The table-driven kernel's batch pass runs one workgroup per
+  //    CU and costs ~1.7 plain passes: from three matrices on it beats a plain pass + a weighted pass per replicate
+  //    (0.63 of a pass each: they walk only the sites a replicate drew).  Its other shapes borrow the per-pair batch
+  //    kernel from three replicates on (those agree with ngd_run()'s to rounding only).
   const bool em_pair = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
-  const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && n_rep >= 3;
-  if ((em_pair || em_borrow) && n_rep + lead >= 2 && e->opt_em_batch) {
+  const bool em_table_batch = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0 && n_rep + lead >= 3;
+  const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape != 0 && n_rep >= 3;
+  if ((em_pair || em_borrow || em_table_batch) && n_rep + lead >= 2 && e->opt_em_batch) {
     const bool fold = lead && e->kernel != NGD_KERNEL_EM_FAITHFUL;
     if (lead && !fold) {
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);

@@ -121,6 +121,12 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
                                const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
                                double *slab, unsigned long long *d_counters /* [2]: += (tile, site) visits, table rounds */);
 
+// accum_em_table.hip, rb (4 or 8) matrices in one pass: d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
+void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
+                                     uint64_t n_sites_eff, const ngd_score &score, int pairwise_del,
+                                     const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks,
+                                     uint64_t sites_per_slice, double *slab, unsigned long long *d_counters);
+
 // rb (4, 8 or 16) replicates in one pass; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
 void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,

@@ -291,7 +291,8 @@ def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
     """ngd_run_job: matrix 0 = ngd_run(NULL) (counts exact, sums to rounding; bit-identical where the plan keeps the
     plain pass), replicates bit-identical to ngd_run(block_map); whatever plan the engine picks: per-block partials
     with the all-ones row (mfma 8 / em with partials on), the EM batch pass (partials off: what large data sets with
-    small blocks get), one list-driven weighted pass per replicate (mfma 7, 1), the streaming kernel."""
+    small blocks get; 16 matrices per pass in the per-pair kernels, 8 in the table-driven one), one list-driven
+    weighted pass per replicate (mfma 7, 1), the streaming kernel."""
     n_ind, n_sites = 21, 1203
     indep = kernel in INDEP_KERNELS
     p = O.synth_indmajor(31, n_ind, n_sites, miss_frac=0.2)
@@ -305,16 +306,14 @@ def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
         assert S.shape == (n_rep + 1, e.n_pairs)
         s0, c0 = e.run()
         assert np.array_equal(Cn[0], c0) and rel_err(S[0], s0) < 1e-12
-        # the table-driven EM engine borrows the per-pair kernel's batch pass from three replicates on (no partials):
-        # those agree with its own weighted pass to rounding, everything else bit for bit
-        borrowed = kernel == "em_table" and not partials and n_rep >= 3
+        # every plan, the table-driven EM kernel's 8-matrices-per-pass form included, gives a replicate the bits
+        # of its own one-replicate pass
         for r in range(n_rep):
             s1, c1 = e.run(maps[r], block_size)
             assert np.array_equal(Cn[r + 1], c1)
-            if borrowed:
-                assert rel_err(S[r + 1], s1) < 1e-12
-            else:
-                assert np.array_equal(S[r + 1], s1)
+            assert np.array_equal(S[r + 1], s1)
+        if kernel == "em_table" and not partials and n_rep >= 2:  # the full-data matrix rides along with weight 1
+            assert np.array_equal(S[0], s0)
         if n_rep:  # and a batch without the leading matrix
             S2, C2 = e.run_batch(maps, block_size)
             assert np.array_equal(S2, S[1:]) and np.array_equal(C2, Cn[1:])
