@@ -90,8 +90,9 @@ def main():
                          "reduce-scatters the valid-site counts (not a BASELINE configuration)")
     ap.add_argument("--miss_frac", type=float, default=0.0, help="fraction of exact (1/3,1/3,1/3) sites in the input")
     ap.add_argument("--serial_tail", action="store_true",
-                    help="N=1: finish a job's host tail (copy out, /cnt, evolutionary model) before the next job's kernels "
-                         "start, instead of running it beside them (the default): ms_per_step is then ONE job's latency")
+                    help="finish a job's tail (copy out, /cnt, evolutionary model; N > 1: the collectives too) before the "
+                         "next job's kernels start, instead of running it beside them (the default): ms_per_step is then "
+                         "ONE job's latency")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -213,6 +214,16 @@ def main():
                 d_cmine = torch.empty(chunk, dtype=torch.int64, device=dev)
                 h_cmine = torch.empty(chunk, dtype=torch.int64).pin_memory()
                 h_cflat = torch.empty(world * chunk, dtype=torch.int64).pin_memory() if not on_gpu else None
+        # Jobs are pipelined two deep: while a worker thread runs job k's tail -- N = 1: copy out + ngd_finish on the
+        # host's libm; N > 1: reduce-scatter, every rank's share of ngd_finish, all-gather -- this thread hands the
+        # GPU job k+1, which accumulates into the other set of buffers.  One worker, so the ranks' collectives keep
+        # one order.
+        import concurrent.futures
+        tail_pool = concurrent.futures.ThreadPoolExecutor(1, initializer=lambda: torch.cuda.set_device(local_rank))
+        tail_job = [None, None]
+        step_no = [0]
+        d_flat_b = [d_flat, torch.zeros_like(d_flat)]
+        d_cflat_b = [d_cflat, torch.zeros_like(d_cflat)]
         if world > 1:
             d_mine = torch.empty(chunk, dtype=torch.float64, device=dev)
             h_mine, h_dist_mine = pin(chunk), pin(chunk)
@@ -222,14 +233,6 @@ def main():
             h_dist_all = pin(world * chunk)
             h_flat = pin(world * chunk) if not on_gpu else None
         else:
-            # N = 1: jobs are pipelined two deep -- while the host copies job k out and runs its tail (worker thread:
-            # ngd_finish on the host's libm), the GPU accumulates job k+1 into the other set of buffers
-            import concurrent.futures
-            tail_pool = concurrent.futures.ThreadPoolExecutor(1)
-            tail_job = [None, None]
-            step_no = [0]
-            d_flat_b = [d_flat, torch.zeros_like(d_flat)]
-            d_cflat_b = [d_cflat, torch.zeros_like(d_cflat)]
             h_all_b = [pin(n_mat, n_pairs), pin(n_mat, n_pairs)]
             h_call_b = [h_call, torch.empty(total, dtype=torch.int64).pin_memory()] if pdel else [None, None]
             dist_all = np.zeros((n_mat, n_pairs))
@@ -271,14 +274,11 @@ def main():
             last["dist"] = h_all[-1].numpy()
             return
         # the job's (partial) sums, every matrix: one engine call per plan
-        if world == 1:
-            buf = step_no[0] & 1
-            step_no[0] += 1
-            if tail_job[buf] is not None:  # the job that used this set of buffers two steps ago has left them
-                tail_job[buf].result()
-            da, dc = d_flat_b[buf][:total].view(n_mat, n_pairs), d_cflat_b[buf][:total].view(n_mat, n_pairs)
-        else:
-            da, dc = d_all_1, d_call_1
+        buf = step_no[0] & 1
+        step_no[0] += 1
+        if tail_job[buf] is not None:  # the job that used this set of buffers two steps ago has left them
+            tail_job[buf].result()
+        da, dc = d_flat_b[buf][:total].view(n_mat, n_pairs), d_cflat_b[buf][:total].view(n_mat, n_pairs)
         if batched:
             first = 0 if fold0 else 1
             if not fold0:
@@ -318,42 +318,50 @@ def main():
                 tail_job[buf] = tail_pool.submit(tail)
             return
         # N > 1: reduce-scatter (partial sums add / disjoint shards meet) -> every rank finishes its share of the
-        # cells on its own host cores -> all-gather of the finished cells
-        if on_gpu:
-            scatter_sum(d_flat, d_mine)
-            h_mine.copy_(d_mine, non_blocking=True)
-            if pdel:  # --pairwise_del: the valid-site counts of the ranks' site ranges add up the same way
-                scatter_sum(d_cflat, d_cmine)
-                h_cmine.copy_(d_cmine, non_blocking=True)
-            # also: the collective has read d_flat before the engine (its own stream) may write it again
-            torch.cuda.current_stream().synchronize()
+        # cells on its own host cores -> all-gather of the finished cells.  (The engine call has synchronised its
+        # stream: this job's sums are in d_flat_b[buf]; the next job writes the other set.)
+        df, dcf = d_flat_b[buf], d_cflat_b[buf]
+
+        def tail_n():
+            if on_gpu:
+                scatter_sum(df, d_mine)
+                h_mine.copy_(d_mine, non_blocking=True)
+                if pdel:  # --pairwise_del: the valid-site counts of the ranks' site ranges add up the same way
+                    scatter_sum(dcf, d_cmine)
+                    h_cmine.copy_(d_cmine, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                h_flat.copy_(df)
+                scatter_sum(h_flat, h_mine)
+                if pdel:
+                    h_cflat.copy_(dcf)
+                    scatter_sum(h_cflat, h_cmine)
+            cnts = h_cmine.numpy().view(np.uint64)[:c_hi - c_lo] if pdel else cnt_flat[c_lo:c_hi]
+            with np.errstate(all="ignore"):
+                N.finish(h_mine.numpy()[:c_hi - c_lo], cnts, 0, W["evol_model"],
+                         out=h_dist_mine.numpy()[:c_hi - c_lo])
+            if on_gpu:
+                d_dist_mine.copy_(h_dist_mine, non_blocking=True)
+                gather_cells(d_dist_all, d_dist_mine)
+                if rank == 0:
+                    h_dist_all.copy_(d_dist_all, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                gather_cells(h_dist_all, h_dist_mine)
+            last["dist"] = h_dist_all.numpy()[:total].reshape(n_mat, n_pairs)[-1]
+
+        if args.serial_tail:
+            tail_n()
         else:
-            h_flat.copy_(d_flat)
-            scatter_sum(h_flat, h_mine)
-            if pdel:
-                h_cflat.copy_(d_cflat)
-                scatter_sum(h_cflat, h_cmine)
-        cnts = h_cmine.numpy().view(np.uint64)[:c_hi - c_lo] if pdel else cnt_flat[c_lo:c_hi]
-        with np.errstate(all="ignore"):
-            N.finish(h_mine.numpy()[:c_hi - c_lo], cnts, 0, W["evol_model"],
-                     out=h_dist_mine.numpy()[:c_hi - c_lo])
-        if on_gpu:
-            d_dist_mine.copy_(h_dist_mine, non_blocking=True)
-            gather_cells(d_dist_all, d_dist_mine)
-            if rank == 0:
-                h_dist_all.copy_(d_dist_all, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-        else:
-            gather_cells(h_dist_all, h_dist_mine)
-        last["dist"] = h_dist_all.numpy()[:total].reshape(n_mat, n_pairs)[-1]
+            tail_job[buf] = tail_pool.submit(tail_n)
 
     def fence():
-        if world > 1:
-            dist.barrier()
-        elif not by_reps:
-            for j in tail_job:  # every job handed in so far is finished, host tail included
+        if not by_reps:
+            for j in tail_job:  # every job handed in so far is finished, tail included
                 if j is not None:
                     j.result()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
 
     def allred(x, op):
@@ -365,10 +373,14 @@ def main():
         if by_reps:
             gather_matrices(d_all if on_gpu else h_all, d_dist if on_gpu else h_dist)
         else:
-            scatter_sum(d_flat if on_gpu else h_flat, d_mine if on_gpu else h_mine)
-            if pdel:
-                scatter_sum(d_cflat if on_gpu else h_cflat, d_cmine if on_gpu else h_cmine)
-            gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
+            def comms_up():  # on the worker: it is the thread that issues the timed collectives
+                scatter_sum(d_flat if on_gpu else h_flat, d_mine if on_gpu else h_mine)
+                if pdel:
+                    scatter_sum(d_cflat if on_gpu else h_cflat, d_cmine if on_gpu else h_cmine)
+                gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
+                if on_gpu:
+                    torch.cuda.current_stream().synchronize()
+            tail_pool.submit(comms_up).result()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -555,9 +567,10 @@ def main():
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
                    "host_tail": ("serial: a job's copy-out and ngd_finish end before the next job's kernels start "
-                                 "(ms_per_step = one job's latency)" if args.serial_tail or world > 1 or by_reps else
-                                 "pipelined: job k's copy-out and ngd_finish (worker thread) run beside job k+1's kernels; "
-                                 "all K jobs, tails included, end inside the timed region"),
+                                 "(ms_per_step = one job's latency)" if args.serial_tail or by_reps else
+                                 "pipelined: job k's tail (copy-out and ngd_finish; N > 1: reduce-scatter, each rank's share "
+                                 "of ngd_finish, all-gather) runs on a worker thread beside job k+1's kernels; all K jobs, "
+                                 "tails included, end inside the timed region"),
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "
                                 "reduce-scatter adds the sums, every rank finishes its 1/%d of the cells on its host, one "

@@ -174,6 +174,16 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 #pragma unroll
             for (int m = 0; m < WM; m++) a[d][m] *= w;
           }
+#if defined(NGD_QB_PROBE)
+          // Diagnostic build (tools/qb_probe.sh), never shipped: what forming q = score . p at consume time would cost
+          // instead of reading the second image QB.  With the contraction index ordered (site quad, genotype, site) a
+          // lane holds the three genotypes of ONE site in three consecutive fragments, so q takes 9 FMAs per lane and
+          // column group per 3 k-groups (6 with a zero score diagonal): NGD_QB_PROBE = 12 (or 8) neutral FP64 FMAs per
+          // k-group on the B fragments stand in for them (x * 1 + 0: results unchanged).
+#pragma unroll
+          for (int q = 0; q < NGD_QB_PROBE; q++)
+            asm volatile("v_fma_f64 %0, %0, 1.0, 0" : "+v"(bq[d][q % WN]));
+#endif
 #pragma unroll
           for (int m = 0; m < WM; m++)
 #pragma unroll
