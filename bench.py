@@ -93,6 +93,7 @@ def main():
                     help="finish a job's tail (copy out, /cnt, evolutionary model; N > 1: the collectives too) before the "
                          "next job's kernels start, instead of running it beside them (the default): ms_per_step is then "
                          "ONE job's latency")
+    ap.add_argument("--pipelined_tail", action="store_true", help="pipeline the tail also for jobs of under 1e5 cells")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -186,6 +187,8 @@ def main():
     # partial sums once, then every replicate is a weighted reduction of them).  When the blocks cover the
     # whole data set the full-data matrix is the all-ones row of the same batch, otherwise it is its own pass.
     batched = W["n_boot"] > 0 and not by_reps
+    # a small job's tail (cfg 2: 19 900 cells, ~0.1 ms) is shorter than the hand-over to a worker thread: it stays serial
+    serial_tail = args.serial_tail or (n_pairs * (W["n_boot"] + 1) < 100_000 and not args.pipelined_tail)
     if by_reps:
         d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
         d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
@@ -312,7 +315,7 @@ def main():
                                  out=dist_all[a:b].reshape(-1))
                 last["dist"] = dist_all[-1]
 
-            if args.serial_tail:
+            if serial_tail:
                 tail()
             else:
                 tail_job[buf] = tail_pool.submit(tail)
@@ -350,7 +353,7 @@ def main():
                 gather_cells(h_dist_all, h_dist_mine)
             last["dist"] = h_dist_all.numpy()[:total].reshape(n_mat, n_pairs)[-1]
 
-        if args.serial_tail:
+        if serial_tail:
             tail_n()
         else:
             tail_job[buf] = tail_pool.submit(tail_n)
@@ -567,7 +570,7 @@ def main():
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
                    "host_tail": ("serial: a job's copy-out and ngd_finish end before the next job's kernels start "
-                                 "(ms_per_step = one job's latency)" if args.serial_tail or by_reps else
+                                 "(ms_per_step = one job's latency)" if serial_tail or by_reps else
                                  "pipelined: job k's tail (copy-out and ngd_finish; N > 1: reduce-scatter, each rank's share "
                                  "of ngd_finish, all-gather) runs on a worker thread beside job k+1's kernels; all K jobs, "
                                  "tails included, end inside the timed region"),

@@ -340,7 +340,10 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
 // register allocation is held to (workgroups per CU x NW / 4)
 // PACK: from the second round of a site on, only the rows in which at least PACK_DENSE pairs are still searching are
 // scanned the plain way; the rest goes through packed_units()
-constexpr int PACK_DENSE = 24;
+#if !defined(NGD_PACK_DENSE)
+#define NGD_PACK_DENSE 24
+#endif
+constexpr int PACK_DENSE = NGD_PACK_DENSE;
 
 // RB > 1: RB matrices in one pass (bootstrap replicates whose blocks are too small for per-block partial results:
 // the EM of a (pair, site) does not depend on the replicate, only its weight does).  Wb[s][RB] = the site's weight in
