@@ -253,8 +253,13 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
   c = __builtin_fma(f1, g1, c);
   c = __builtin_fma(f2, g2, c);
   if (T) {
+    if (RB == 1 || __builtin_fabs(c) <= 1.7976931348623157e308) {
 #pragma unroll
-    for (int b = 0; b < RB; b++) accr[b] = accr[b] + (WEIGHTED ? c * wv[b] : c);
+      for (int b = 0; b < RB; b++) accr[b] = accr[b] + (WEIGHTED ? c * wv[b] : c);
+    } else {  // NaN (an all-zero site): only the matrices that draw the site take it -- 0 x NaN must add nothing
+#pragma unroll
+      for (int b = 0; b < RB; b++) accr[b] = wv[b] != 0.0 ? accr[b] + c * wv[b] : accr[b];
+    }
     todo &= ~(1u << r);
   }
 }
@@ -313,9 +318,15 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
       const ngd_d2 v0 = mail[0], v1 = mail[1], v2 = mail[2], v3 = mail[3];
       const double v[8] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
 #pragma unroll
-      for (int q = 0; q < 8; q++)
+      for (int q = 0; q < 8; q++) {
+        if (RB == 1 || __builtin_fabs(v[q]) <= 1.7976931348623157e308) {
 #pragma unroll
-        for (int b = 0; b < RB; b++) acc[q][b] = acc[q][b] + (WEIGHTED ? v[q] * wv[b] : v[q]);
+          for (int b = 0; b < RB; b++) acc[q][b] = acc[q][b] + (WEIGHTED ? v[q] * wv[b] : v[q]);
+        } else {  // (as in scan_row: a NaN term reaches only the matrices whose weight is not zero)
+#pragma unroll
+          for (int b = 0; b < RB; b++) acc[q][b] = wv[b] != 0.0 ? acc[q][b] + v[q] * wv[b] : acc[q][b];
+        }
+      }
       todo &= ~((uint32_t)(done >> (rank * 8)) & 0xffu);
     }
     pm &= ~__builtin_amdgcn_ballot_w64(sel);
