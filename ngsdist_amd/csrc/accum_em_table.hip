@@ -55,6 +55,7 @@ struct alignas(16) em_tables {
   // (its own factor R_t is still >= e^tole there, and a column's is never below 1): the plain scan skips those steps
   unsigned long long row_nostop[4];
   uint8_t unit_col[PACK ? 8 * 8 : 8];
+  uint8_t poison[2][TS];  // RB > 1, kernel end: bit b = matrix b drew a site at which this row / column was all zero
 };
 
 // Workgroup barrier that waits for this wavefront's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. the
@@ -252,14 +253,9 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
   double c = f0 * g0;
   c = __builtin_fma(f1, g1, c);
   c = __builtin_fma(f2, g2, c);
-  if (T) {
-    if (RB == 1 || __builtin_fabs(c) <= 1.7976931348623157e308) {
+  if (T) {  // (RB > 1: the term is finite -- the individuals that would make it NaN are handled apart, see `poison`)
 #pragma unroll
-      for (int b = 0; b < RB; b++) accr[b] = accr[b] + (WEIGHTED ? c * wv[b] : c);
-    } else {  // NaN (an all-zero site): only the matrices that draw the site take it -- 0 x NaN must add nothing
-#pragma unroll
-      for (int b = 0; b < RB; b++) accr[b] = wv[b] != 0.0 ? accr[b] + c * wv[b] : accr[b];
-    }
+    for (int b = 0; b < RB; b++) accr[b] = accr[b] + (WEIGHTED ? c * wv[b] : c);
     todo &= ~(1u << r);
   }
 }
@@ -318,15 +314,9 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
       const ngd_d2 v0 = mail[0], v1 = mail[1], v2 = mail[2], v3 = mail[3];
       const double v[8] = {v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        if (RB == 1 || __builtin_fabs(v[q]) <= 1.7976931348623157e308) {
+      for (int q = 0; q < 8; q++)
 #pragma unroll
-          for (int b = 0; b < RB; b++) acc[q][b] = acc[q][b] + (WEIGHTED ? v[q] * wv[b] : v[q]);
-        } else {  // (as in scan_row: a NaN term reaches only the matrices whose weight is not zero)
-#pragma unroll
-          for (int b = 0; b < RB; b++) acc[q][b] = wv[b] != 0.0 ? acc[q][b] + v[q] * wv[b] : acc[q][b];
-        }
-      }
+        for (int b = 0; b < RB; b++) acc[q][b] = acc[q][b] + (WEIGHTED ? v[q] * wv[b] : v[q]);
       todo &= ~((uint32_t)(done >> (rank * 8)) & 0xffu);
     }
     pm &= ~__builtin_amdgcn_ballot_w64(sel);
@@ -418,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   if (tid < 2) L.more[tid] = 0;
   uint32_t round = 0;  // table rounds so far (all sites): parity selects the flag word
   uint32_t sites_done = 0;
+  uint32_t poison = 0;  // RB > 1, lane = the individual this lane builds: matrices that drew a site where it is all zero
 
 #if defined(NGD_EMT_STAMPS)
   double stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -443,14 +434,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       wgt = (double)m;
     }
     wv[0] = wgt;
+    uint32_t nz = 1;  // bit b: matrix b draws this site
     if (RB > 1) {
-      bool any = false;
+      nz = 0;
 #pragma unroll
       for (int b = 0; b < RB; b++) {
         wv[b] = Wb[s * RB + b];
-        any = any || wv[b] != 0.0;
+        nz |= (wv[b] != 0.0 ? 1u : 0u) << b;
       }
-      if (!any) continue;  // drawn by none of these replicates
+      nz = __builtin_amdgcn_readfirstlane(nz);
+      if (!nz) continue;  // drawn by none of these replicates
     }
     // v = g^(t0 + seg*SEG): the power one step before this wavefront's first step of the round; gch = g^CH
     double v[3] = {1.0, 1.0, 1.0}, gch[3];
@@ -470,7 +463,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
         for (int x = 0; x < 3; x++) sq[x] *= sq[x];
       }
     }
-    const bool miss = PDEL && ngd_miss(g[0], g[1], g[2]);
+    bool miss = PDEL && ngd_miss(g[0], g[1], g[2]);
+    if (RB > 1 && !miss) {
+      // Several matrices per pass: a NaN term (an all-zero individual: 0/0 in normalize(), as on the CPU) would reach the
+      // matrices that do NOT draw this site as 0 x NaN.  Such an individual is tabled like a missing one (its pairs stop
+      // at once and add exactly 0) and remembered per matrix that draws the site: its pairs are set to NaN at the end.
+      const double a0 = (g[0] + g[1]) + g[2];
+      if (!(a0 > 0.0 && a0 <= 1.7976931348623157e308)) {
+        miss = true;
+        poison |= nz;
+      }
+    }
     uint32_t todo = live;
     sites_done++;
     EMT_STAMP(2);  // per-site set-up (powers)
@@ -592,6 +595,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #pragma unroll
   for (int r = 0; r < RPW && r < 8; r++) acc[r][0] = stamp_sum[r];
 #endif
+  if (RB > 1) {  // (uniform: RB is a template parameter)
+    if (seg == 0) L.poison[is_row ? 0 : 1][lane] = (uint8_t)poison;  // every wavefront of a role saw the same individuals
+    wg_barrier();
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+      const uint32_t pz = (uint32_t)L.poison[0][wave * RPW + r] | (uint32_t)L.poison[1][lane];
+#pragma unroll
+      for (int b = 0; b < RB; b++)
+        if ((pz >> b) & 1) acc[r][b] = __builtin_nan("");
+    }
+  }
 #pragma unroll
   for (int r = 0; r < RPW; r++)
 #pragma unroll
