@@ -19,6 +19,11 @@
 // rare; step 50 is forced).  Against the per-pair form (k_accum_em<fast>: ~16 FP64 instructions per
 // step and pair, 46 per pair-site at the end) this is 2 per step and ~10 per round at the end.
 //
+// The default form (PACK, below) changes how the rounds AFTER a site's first are worked -- the pairs still searching
+// then sit in a few columns and rows, so they are packed 8 columns x a wavefront's 8 rows to a unit instead of being
+// scanned row by row with most lanes idle -- skips the 8-step blocks in which a row cannot stop at all, and orders a
+// row's LDS reads so that it waits for one round trip; sums are bit-identical to the plain form's (shape 4).
+//
 // Same arithmetic contract as the fast form: the stopping step is the reference's except where the
 // criterion is within rounding of the tolerance; sums agree to ~1e-13 relative (bar: 1e-9).
 // Missing sites under --pairwise_del (ngsDist.cpp:335-338) take Q = +inf / R = 0 and f = g = 0 at
@@ -340,7 +345,8 @@ __device__ __forceinline__ void packed_units(em_tables<CH, true> &L, uint32_t wa
 // NW wavefronts per workgroup (64 / NW rows each), CH steps per table round, WPS = waves per SIMD the
 // register allocation is held to (workgroups per CU x NW / 4)
 // PACK: from the second round of a site on, only the rows in which at least PACK_DENSE pairs are still searching are
-// scanned the plain way; the rest goes through packed_units()
+// scanned the plain way; the rest goes through packed_units() ([measured] tools/em_dense_sweep.sh, 1000 x 2e4: 8: 46.2 ms,
+// 16: 44.1, 24: 44.5, 32: 44.8, 48: 47.3, no plain rows at all: 61.4)
 #if !defined(NGD_PACK_DENSE)
 #define NGD_PACK_DENSE 24
 #endif
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 }  // namespace
 
 // shape: 0 = 8 wavefronts x 8 rows, 16 steps per round, 4 waves per SIMD, a site's later rounds in packed units
-//            (default: [measured] 1000 x 2e4, ms per launch: 46.0; shape 4, the same with every round scanned row by
+//            (default: [measured] 1000 x 2e4, ms per launch: 44.5; shape 4, the same with every round scanned row by
 //            row: 49.2 -- same bits; shape 1: 59.6; 2: 51.9; 3: 51.3; k_accum_em<fast> 122.7);
 //        1 = 4 wavefronts x 16 rows, 16 steps, 2 waves per SIMD (register-rich);  2 / 3 = 0's and 1's shapes with 12
 //            steps per round, rows only
