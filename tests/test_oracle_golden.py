@@ -92,3 +92,23 @@ def test_em2_bit_identical_to_reference_em2():
     for k in range(n):
         s, _ = O.em2(a[k], b[k])
         assert np.array_equal(s, ref[k], equal_nan=True), k
+
+
+@pytest.mark.skipif(O.ref_lib() is None, reason="oracle/_ref not built (reference tree absent)")
+def test_pair_loop_on_the_references_own_em2_carries_the_same_bits():
+    """oracle.use_reference_em2: the threaded pair loop (ngsDist.cpp:333-364 as restated) calling the reference's own
+    em2() -- emOptim2.cpp compiled from where it lies -- instead of the restated one: every sum and count identical,
+    missing data, --pairwise_del and a bootstrap replicate included (what bench.py's "reference-em2" baseline times)."""
+    p = O.synth_indmajor(21, 9, 700, miss_frac=0.1)
+    p[2, 5] = 0.0  # an all-zero site: NaN sums in both
+    src = O.boot_site_src(O.Taus(3).block_map(70), 10)
+    cases = [dict(), dict(pairwise_del=True), dict(site_src=src, n_sites=700)]
+    port = [O.all_pairs(p, indep_geno=False, n_threads=4, **kw) for kw in cases]
+    assert O.use_reference_em2(True)
+    try:
+        ref = [O.all_pairs(p, indep_geno=False, n_threads=4, **kw) for kw in cases]
+    finally:
+        O.use_reference_em2(False)
+    for (s0, c0), (s1, c1) in zip(port, ref):
+        assert np.array_equal(s0, s1, equal_nan=True) and np.array_equal(c0, c1)
+    assert np.isnan(port[0][0]).any() and not np.isnan(port[0][0]).all()
