@@ -900,6 +900,8 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
     const bool lead = lead_full && c0 == 0;
     const uint32_t q0 = c0 - ((lead_full && c0 > 0) ? 1u : 0u);  // first replicate of the chunk
     const uint32_t nq = nr - (lead ? 1u : 0u);                     // replicates in the chunk
+    if (e->opt_boot_max_bytes && (uint64_t)b_ks * rb * plane * 8 > e->opt_boot_max_bytes)  // the caller's scratch budget
+      return fail(NGD_E_NOMEM, "EM batch pass: result planes exceed NGD_OPT_BOOT_MAX_BYTES");
     int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (uint64_t)b_ks * rb * plane);
     if (rc) return rc;
     rc = ensure_cap(e, &e->d_W, &e->cap_W, g.n_sites * (uint64_t)rb);
@@ -1038,8 +1040,20 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
       if (rc) return rc;
     }
-    return em_batch_impl(e, mult, mult_max.data() + lead, drawn.data() + lead, n_rep, fold, n_blocks, block_size,
-                         fold ? d_sum : rep_sum, fold ? d_cnt : rep_cnt, lead && !fold);
+    rc = em_batch_impl(e, mult, mult_max.data() + lead, drawn.data() + lead, n_rep, fold, n_blocks, block_size,
+                       fold ? d_sum : rep_sum, fold ? d_cnt : rep_cnt, lead && !fold);
+    // the batch pass wants RB result planes per slice: if the device cannot hold them (very many individuals), the
+    // matrices are computed one pass each instead (the allocation is tried before anything is launched)
+    if (rc != NGD_E_NOMEM) return rc;
+    (void)hipGetLastError();
+    if (lead && !fold) {  // matrix 0 is done already
+      for (uint32_t r = 0; r < n_rep; r++) {
+        rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[lead + r], n_blocks, block_size, drawn[lead + r],
+                       rep_sum + (uint64_t)r * n_pairs, rep_cnt + (uint64_t)r * n_pairs, true);
+        if (rc) return rc;
+      }
+      return NGD_OK;
+    }
   }
   // 3. one accumulation pass per matrix
   if (lead) {

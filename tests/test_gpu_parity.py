@@ -325,6 +325,23 @@ def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
         assert np.array_equal(Cn[-1], co) and rel_err(S[-1], so) < RTOL
 
 
+@pytest.mark.parametrize("kernel", ["em_table", "em_fast", "em_faithful"])
+def test_em_batch_pass_that_does_not_fit_falls_back_to_one_pass_per_matrix(kernel):
+    """the EM batch pass needs RB result planes per slice; when they exceed the scratch budget (NGD_OPT_BOOT_MAX_BYTES,
+    or the device) the job is computed one pass per matrix instead -- same bits either way"""
+    n_ind, n_sites, B = 40, 600, 3
+    p = O.synth_indmajor(8, n_ind, n_sites, miss_frac=0.1)
+    maps = np.stack([N().Taus(9 + k).block_map(n_sites // B) for k in range(5)])
+    with N().Engine(n_ind, n_sites, indep_geno=False, kernel=kernel, pairwise_del=True) as e:
+        e.set_option("boot_partials", 0)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, B)
+        e.set_option("boot_max_bytes", 4096)
+        S2, C2 = e.run_job(maps, B)
+    assert np.array_equal(Cn, C2)
+    assert np.array_equal(S[1:], S2[1:]) and rel_err(S2[0], S[0]) < 1e-12
+
+
 def test_heavy_multiplicity_counts():
     """all blocks map to block 0 -> multiplicity n_blocks on a few sites (bit-plane path)."""
     n_ind, n_sites, B = 5, 640, 2
