@@ -222,10 +222,12 @@ int ngd_drop_caches(ngd_engine *e);
  * Every plan returns the same counts and sums equal to rounding ("Plans"). */
 #define NGD_OPT_BOOT_PARTIALS 1  /* [1] bootstrap replicates from per-block partial (sum, cnt): 0 never, 1 when they */
                                  /*     fit and pay for their allocation, 2 allocate even a large slab at once       */
-#define NGD_OPT_BOOT_MAX_BYTES 2 /* [0 = 85 % of free device memory] budget of those partials                        */
+#define NGD_OPT_BOOT_MAX_BYTES 2 /* [0 = 85 % of free device memory] budget of those partials (and, when set, of the     */
+                                 /*     EM batch pass's result planes: beyond it, one pass per matrix)                */
 #define NGD_OPT_BOOT_WG 3        /* [4096] workgroups wanted in the pass that fills them                             */
 #define NGD_OPT_BOOT_UNALIGNED 4 /* [1] MFMA path: partials also for block sizes that are not multiples of 4 sites   */
-#define NGD_OPT_EM_BATCH 5       /* [1] per-pair EM kernels without partials: up to 16 matrices per accumulation pass */
+#define NGD_OPT_EM_BATCH 5       /* [1] EM kernels without partials: up to 16 (per-pair) / 8 (table-driven) matrices  */
+                                 /*     per accumulation pass                                                         */
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
