@@ -203,14 +203,6 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (dev < 0) HIPCHK(hipGetDevice(&dev));
   if (dev >= n_dev) return fail(NGD_E_NODEVICE, "ngd_create: device ordinal out of range");
   HIPCHK(hipSetDevice(dev));
-  {
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const uint64_t n_pad = (cfg->n_ind + 127) / 128 * 128;
-    const uint64_t least = ngd_n_pairs(cfg->n_ind) * 16 + 8 * n_pad * n_pad * 8;  // results + the fewest slab planes
-    if (least > total_b) return fail(NGD_E_NOMEM, "ngd_create: the result arrays of this many individuals exceed the device's memory");
-  }
-
   int kernel = cfg->kernel;
   if (cfg->indep_geno) {
     if (kernel == NGD_KERNEL_AUTO) kernel = NGD_KERNEL_MFMA;
@@ -225,6 +217,19 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       return fail(NGD_E_INVALID, "ngd_create: kernel does not serve the EM path");
   }
 
+  {  // before any list is built: the two result arrays + the fewest slab planes this kernel works with must fit at all
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t n_pad = (cfg->n_ind + 127) / 128 * 128;
+    // tens of thousands of individuals: the MFMA kernel's 8 planes of n_pad^2 doubles (its XCD deal wants 8 slices) no
+    // longer fit beside the results -- `auto` then means the streaming kernel, which writes the results directly
+    if (cfg->kernel == NGD_KERNEL_AUTO && kernel == NGD_KERNEL_MFMA &&
+        ngd_n_pairs(cfg->n_ind) * 16 + 8 * n_pad * n_pad * 8 > total_b)
+      kernel = NGD_KERNEL_STREAM;
+    const uint64_t planes = kernel == NGD_KERNEL_MFMA ? 8 : kernel == NGD_KERNEL_STREAM ? 0 : 1;
+    if (ngd_n_pairs(cfg->n_ind) * 16 + planes * n_pad * n_pad * 8 > total_b)
+      return fail(NGD_E_NOMEM, "ngd_create: the result arrays and slabs of this many individuals exceed the device's memory");
+  }
   ngd_engine *e = new (std::nothrow) ngd_engine();
   if (!e) return fail(NGD_E_NOMEM, "ngd_create: host allocation failed");
   e->cfg = *cfg;
