@@ -43,7 +43,9 @@ extern "C" {
 #define NGD_E_NAN (-6)      /* "NaN found! Is the file format correct?" (read_data.cpp:42-45) */
 
 /* which kernel serves the per-pair accumulation */
-#define NGD_KERNEL_AUTO 0   /* indep: MFMA; EM: the table kernel above 32 individuals, the fast per-pair kernel up to 32 */
+#define NGD_KERNEL_AUTO 0   /* indep: MFMA (the streaming kernel where the MFMA kernel's 8 slab planes of n_pad^2 doubles  */
+                            /* cannot fit the device: tens of thousands of individuals); EM: the table kernel above 32     */
+                            /* individuals, the fast per-pair kernel up to 32                                              */
 #define NGD_KERNEL_STREAM 1 /* indep: one wavefront per pair, streams 48 B per pair-site */
 #define NGD_KERNEL_MFMA 2   /* indep: FP64 MFMA tiles over the (pair, site) contraction */
 #define NGD_KERNEL_EM_FAITHFUL 3 /* EM: iterates bit-identical to emOptim2.cpp */
