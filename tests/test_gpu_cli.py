@@ -287,6 +287,33 @@ def test_bench_line_contract(tmp_path):
     assert d["spot_check"]["max_rel_err_vs_oracle"] < 1e-9
 
 
+def test_bench_pipelined_tail_and_em_roofline_fields(tmp_path):
+    """N = 1: a job's copy-out and host tail on the worker thread beside the next job's kernels (forced here on a small
+    job: --pipelined_tail) gives the same line as --serial_tail, a bootstrap job included; the EM line carries the
+    active-lane and issue-slot figures (or says why not) and the reference-em2 CPU baseline."""
+    import json
+    import sys
+
+    def line(*args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"] + list(args),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+
+    for extra in (["--workload", "cfg2", "--n_sites", "20000"], ["--workload", "cfg5", "--n_sites", "20000"]):
+        a = line(*extra, "--no_cpu", "--pipelined_tail")
+        b = line(*extra, "--no_cpu", "--serial_tail")
+        assert a["valid"] and b["valid"] and a["config"]["host_tail"].startswith("pipelined")
+        assert b["config"]["host_tail"].startswith("serial")
+        assert a["spot_check"]["max_rel_err_vs_oracle"] == b["spot_check"]["max_rel_err_vs_oracle"]
+    d = line("--workload", "cfg4", "--n_sites", "3000", "--cpu_sites", "60")
+    assert d["valid"] and d["roofline"]["kernel"] == "k_accum_em_table" and "frac_kind" in d["roofline"]
+    if d["roofline"]["frac"] is not None:
+        assert d["roofline"]["frac"] == d["roofline"]["active_lane_frac"] <= d["roofline"]["issue_slot_frac"]
+    ref = d["cpu_baseline"]["reference_em2"]
+    assert ref.get("kind") == "reference-em2" and ref["bit_identical_to_port"] is True, ref
+
+
 def test_binary_input_size_errors_and_gz_binary(tmp_path):
     """plain binary files are read with pread on several threads, gz-compressed binary ones (and stdin) through
     gzread: same bytes out; a file with trailing bytes is the reference's "not at EOF", a wrong size its
