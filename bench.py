@@ -93,7 +93,8 @@ def main():
                     help="finish a job's tail (copy out, /cnt, evolutionary model; N > 1: the collectives too) before the "
                          "next job's kernels start, instead of running it beside them (the default): ms_per_step is then "
                          "ONE job's latency")
-    ap.add_argument("--pipelined_tail", action="store_true", help="pipeline the tail also for jobs of under 1e5 cells")
+    ap.add_argument("--pipelined_tail", action="store_true",
+                    help="pipeline the tail also where the default is serial: jobs of under 1e5 cells, and N > 1")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -187,8 +188,10 @@ def main():
     # partial sums once, then every replicate is a weighted reduction of them).  When the blocks cover the
     # whole data set the full-data matrix is the all-ones row of the same batch, otherwise it is its own pass.
     batched = W["n_boot"] > 0 and not by_reps
-    # a small job's tail (cfg 2: 19 900 cells, ~0.1 ms) is shorter than the hand-over to a worker thread: it stays serial
-    serial_tail = args.serial_tail or (n_pairs * (W["n_boot"] + 1) < 100_000 and not args.pipelined_tail)
+    # a small job's tail (cfg 2: 19 900 cells, ~0.1 ms) is shorter than the hand-over to a worker thread: it stays serial.
+    # N > 1: the pipelined form (collectives on the worker thread) has only been rehearsed over gloo -- no multi-GPU
+    # hardware was available to this build -- so the default there is the plain form, every collective on the main thread
+    serial_tail = args.serial_tail or ((n_pairs * (W["n_boot"] + 1) < 100_000 or world > 1) and not args.pipelined_tail)
     if by_reps:
         d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
         d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
@@ -383,7 +386,10 @@ def main():
                 gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
                 if on_gpu:
                     torch.cuda.current_stream().synchronize()
-            tail_pool.submit(comms_up).result()
+            if serial_tail:
+                comms_up()
+            else:
+                tail_pool.submit(comms_up).result()
     for _ in range(args.warmup):
         step(False)
     fence()

@@ -49,6 +49,15 @@ def test_two_ranks_em_path_reduced_sites():
     assert out["valid"] is True
 
 
+def test_two_ranks_with_the_tail_on_the_worker_thread():
+    # --pipelined_tail at N > 1: reduce-scatter, each rank's share of ngd_finish and the all-gather on the worker thread
+    # beside the next job's kernels (default at N = 1; opt-in here until it has run over RCCL)
+    for w in (["--workload", "cfg3", "--n_sites", "100000"], ["--workload", "cfg5", "--n_sites", "50000"]):
+        out = _bench(*w, "--pipelined_tail")
+        assert out["valid"] is True and out["config"]["host_tail"].startswith("pipelined")
+        assert _bench(*w)["config"]["host_tail"].startswith("serial")
+
+
 def test_two_ranks_pairwise_del_counts_are_reduced():
     # counts differ per pair: they go through the same reduce-scatter as the sums (ngsDist.cpp:335-338, :362)
     out = _bench("--workload", "cfg2", "--pairwise_del", "--miss_frac", "0.1")
