@@ -128,6 +128,59 @@ def test_testA_shape_called_genotypes(tmp_path):
         assert got == exp
 
 
+def test_the_references_test_script_matrix_on_likelihood_inputs(tmp_path):
+    """examples/test.sh beyond its three called-genotype runs: the same 24 x 10 000 shape as genotype LIKELIHOODS in the
+    script's three encodings -- BEAGLE text (header line, marker + two allele columns, --pos file), binary doubles,
+    posterior-probability text (two prefix columns) -- each through its five command lines: plain, --n_boot_rep 5 at the
+    default block size 1 and at --boot_block_size 10 (the EM path, the reference's default), the latter with
+    --call_geno and with --call_geno --N_thresh 0.3 --call_thresh 0.9; always --n_threads 10 --seed 12345 --labels.  The
+    script's own inputs come from ngsSim + ANGSD (absent), so the data are synthetic and the expected text is the
+    oracle's restatement of the reference's main loop: same bytes, or (likelihood sums differ in their last bits)
+    every cell within 2e-10."""
+    n_ind, n_sites = 24, 10000
+    _, lpath, labels = _testA_like(tmp_path, n_sites=10)  # the label file (and a small genotype file not used here)
+    p = O.synth_indmajor(17, n_ind, n_sites, miss_frac=0.03)
+    sm = np.ascontiguousarray(p.transpose(1, 0, 2))  # [site][ind][3], the file order
+    beagle, binf, post, pos = (str(tmp_path / n) for n in ("testA_2.beagle.gz", "testA_32.geno", "testA_8.geno.gz", "testA.pos"))
+    fmt = lambda row: "\t".join("%.17g" % x for x in row.reshape(-1))
+    with gzip.open(beagle, "wt") as fh:
+        fh.write("marker\tallele1\tallele2\t" + "\t".join("Ind%d\tInd%d\tInd%d" % (i, i, i) for i in range(n_ind)) + "\n")
+        for k in range(n_sites):
+            fh.write("chrSIM_%d\t%d\t%d\t" % (k + 1, k % 4, (k + 1) % 4) + fmt(sm[k]) + "\n")
+    with open(pos, "w") as fh:
+        fh.write("".join("chrSIM\t%d\n" % (k + 1) for k in range(n_sites)))
+    sm.tofile(binf)
+    with gzip.open(post, "wt") as fh:
+        for k in range(n_sites):
+            fh.write("chrSIM\t%d\t" % (k + 1) + fmt(sm[k]) + "\n")
+    runs = [([], {}), (["--n_boot_rep", 5], dict(n_boot_rep=5)),
+            (["--n_boot_rep", 5, "--boot_block_size", 10], dict(n_boot_rep=5, boot_block_size=10)),
+            (["--n_boot_rep", 5, "--boot_block_size", 10, "--call_geno"], dict(n_boot_rep=5, boot_block_size=10, call=(0.0, 0.0))),
+            (["--n_boot_rep", 5, "--boot_block_size", 10, "--call_geno", "--N_thresh", 0.3, "--call_thresh", 0.9],
+             dict(n_boot_rep=5, boot_block_size=10, call=(0.3, 0.9)))]
+    same = 0
+    for path, extra_in, text in ((beagle, ["--pos", pos], True), (binf, [], False), (post, [], True)):
+        prepared = {}
+        for flags, kw in runs:
+            kw = dict(kw)
+            call = kw.pop("call", None)
+            if call not in prepared:  # the reference prepares (and calls) at load time: once per calling rule
+                ck = dict(call_geno=call is not None, N_thresh=call[0] if call else 0.0, call_thresh=call[1] if call else 0.0)
+                prepared[call] = O.load_text(path, n_ind, n_sites, in_probs=True, **ck) if text else \
+                    O.prep_binary(sm, n_ind, n_sites, **ck)
+            exp = O.run_reference_flow(prepared[call], labels=labels, seed=12345, n_threads=16,
+                                       indep_geno=call is not None, **kw)  # --call_geno forces --indep_geno (ngsDist.cpp:55-65)
+            got = cli(tmp_path, "--geno", path, "--probs", "--n_ind", n_ind, "--n_sites", n_sites, "--labels", lpath,
+                      "--n_threads", 10, "--seed", 12345, *extra_in, *flags)
+            if got == exp:
+                same += 1
+            else:
+                a, b = cells(got), cells(exp)
+                assert a.shape == b.shape and [ln.split("\t")[0] for ln in got.splitlines()] == [ln.split("\t")[0] for ln in exp.splitlines()]
+                assert np.all((np.abs(a - b) <= 2e-10 * np.maximum(1.0, np.abs(b))) | (a == b) | (np.isnan(a) & np.isnan(b))), (path, flags)
+    assert same >= 6  # the called-genotype runs are dyadic sums: identical bytes whatever the order of additions
+
+
 def test_text_gl_with_header_and_two_gpu_shards_on_one_device(tmp_path):
     n_ind, n_sites = 150, 300  # two tile rows -> 3 pair tiles
     p_raw = O.synth_indmajor(31, n_ind, n_sites)  # [i][s][3]
