@@ -6,9 +6,12 @@
 One "step" = one job of the hot path over the resident data set: accumulation
 kernel(s) -> deterministic slab reduction -> copy to host -> /cnt and
 evolutionary-model transform with the host's libm (the tail of gen_dist,
-ngsDist.cpp:372-401), with ONE collective per job when N > 1.
+ngsDist.cpp:372-401), with a reduce-scatter and an all-gather per job when N > 1.
 Inputs are synthetic (counter-based generator), generated ON the GPU
-before the timed region.
+before the timed region.  At N = 1 a job's tail runs on a worker thread beside
+the NEXT job's kernels (two jobs in flight; every tail ends inside the timed
+region; --serial_tail times one job's latency instead).  `--gpus N` without a
+RANK in the environment starts the N ranks itself (torch.distributed.run).
 
 N > 1 (--shard): the SAME job at every N unless --shard replicates is asked for.
   sites (default; strong scaling): each GPU holds 1/N of the sites of all individuals and computes every pair over
