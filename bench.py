@@ -8,10 +8,13 @@ kernel(s) -> deterministic slab reduction -> copy to host -> /cnt and
 evolutionary-model transform with the host's libm (the tail of gen_dist,
 ngsDist.cpp:372-401), with a reduce-scatter and an all-gather per job when N > 1.
 Inputs are synthetic (counter-based generator), generated ON the GPU
-before the timed region.  At N = 1 a job's tail runs on a worker thread beside
-the NEXT job's kernels (two jobs in flight; every tail ends inside the timed
-region; --serial_tail times one job's latency instead).  `--gpus N` without a
-RANK in the environment starts the N ranks itself (torch.distributed.run).
+before the timed region.  The timed K steps -- `value`, `ms_per_step` -- run one job
+at a time: a job's tail ends before the next job's kernels start, so ms_per_step
+is ONE job's latency, what a real run (one job) sees.  At N = 1 a second region
+of K steps then runs the jobs two deep (job k's tail on a worker thread beside
+job k+1's kernels) and is reported apart, as `pipelined` (throughput of a stream
+of jobs; never `value`).  `--gpus N` without a RANK in the environment starts the
+N ranks itself (torch.distributed.run).
 
 N > 1 (--shard): the SAME job at every N unless --shard replicates is asked for.
   sites (default; strong scaling): each GPU holds 1/N of the sites of all individuals and computes every pair over
@@ -93,11 +96,17 @@ def main():
                          "reduce-scatters the valid-site counts (not a BASELINE configuration)")
     ap.add_argument("--miss_frac", type=float, default=0.0, help="fraction of exact (1/3,1/3,1/3) sites in the input")
     ap.add_argument("--serial_tail", action="store_true",
-                    help="finish a job's tail (copy out, /cnt, evolutionary model; N > 1: the collectives too) before the "
-                         "next job's kernels start, instead of running it beside them (the default): ms_per_step is then "
-                         "ONE job's latency")
+                    help="only the headline region (one job at a time: a job's tail -- copy out, /cnt, evolutionary model; "
+                         "N > 1: the collectives too -- ends before the next job's kernels start); skip the second, "
+                         "pipelined region")
     ap.add_argument("--pipelined_tail", action="store_true",
-                    help="pipeline the tail also where the default is serial: jobs of under 1e5 cells, and N > 1")
+                    help="run the second (pipelined) region also where it is skipped by default: jobs of under 1e5 cells, "
+                         "and N > 1 (collectives on the worker thread: rehearsed over gloo only)")
+    ap.add_argument("--vary_jobs", action="store_true",
+                    help="test path: odd steps compute another job than even steps (a bootstrap replicate instead of the "
+                         "full-data matrix / the replicates in reverse order), every tail records a checksum of its whole "
+                         "result, and the pipelined region's checksums must equal the serial region's step by step -- a "
+                         "mix-up of the two buffer sets cannot pass (not a bench line)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -194,7 +203,11 @@ def main():
     # a small job's tail (cfg 2: 19 900 cells, ~0.1 ms) is shorter than the hand-over to a worker thread: it stays serial.
     # N > 1: the pipelined form (collectives on the worker thread) has only been rehearsed over gloo -- no multi-GPU
     # hardware was available to this build -- so the default there is the plain form, every collective on the main thread
-    serial_tail = args.serial_tail or ((n_pairs * (W["n_boot"] + 1) < 100_000 or world > 1) and not args.pipelined_tail)
+    # the headline region is always serial (one job's latency); the second region pipelines the jobs two deep
+    run_pipelined = not by_reps and not args.serial_tail and (
+        args.pipelined_tail or (n_pairs * (W["n_boot"] + 1) >= 100_000 and world == 1))
+    mode = {"serial": True}
+    sums_seen = {"serial": [], "pipelined": []}  # --vary_jobs: one checksum per step and region
     if by_reps:
         d_sum = torch.zeros(n_pairs, dtype=torch.float64, device=dev)
         d_cnt = torch.zeros(n_pairs, dtype=torch.int64, device=dev)
@@ -255,13 +268,33 @@ def main():
         rows = ([np.ones(n_blocks, dtype=np.uint32)] if fold0 else []) + mults[1:]
         mult_all = np.ascontiguousarray(np.stack(rows)[:, blk_lo:blk_hi] if by_sites else np.stack(rows))
 
+    # --vary_jobs: the other job (odd steps counted from the END of a region, so that a region's last step is the
+    # workload's own job and the spot check below applies to it)
+    if args.vary_jobs:
+        if by_reps:
+            raise SystemExit("bench.py: --vary_jobs is wired for the sharded and single-GPU flows, not --shard replicates")
+        if batched:
+            keep = 1 if fold0 else 0
+            mult_alt = np.ascontiguousarray(np.concatenate([mult_all[:keep], mult_all[keep:][::-1]]))
+        else:
+            alt_B = 16
+            alt_rng = N.Taus(777)
+            alt_map = alt_rng.block_map(n_sites // alt_B)
+            alt_mult_all = np.bincount(alt_map.astype(np.int64), minlength=n_sites // alt_B).astype(np.uint32)
+            alt_mult = np.ascontiguousarray(alt_mult_all[lo // alt_B:(hi if hi < n_sites else n_sites) // alt_B])
+            cnt_flat_alt = np.full(n_pairs, (n_sites // alt_B) * alt_B, dtype=np.uint64)
+
+    def checksum(a):
+        v = np.ascontiguousarray(a).reshape(-1).view(np.uint64)
+        return int(np.bitwise_xor.reduce(v[::max(1, v.size // 65536)]))
+
     def record_timing():
         t = eng.timing()
         red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
         if t["launches"]:  # replicates served from cached block partial sums launch no accumulation
             acc_ms.append(t["ms_accum"] / t["launches"]); pair_sites.append(t["pair_sites"] / t["launches"])
 
-    def step(record):
+    def step(record, variant=0):
         eng.drop_caches()  # bootstrap block partial sums are recomputed in every step (no carried work)
         if by_reps:
             # this rank's matrix, start to finish; then ONE collective puts the N finished matrices together
@@ -294,12 +327,16 @@ def main():
                 eng.run_device(da[0].data_ptr(), dc[0].data_ptr())
                 if record:
                     record_timing()
-            eng.run_batch(mult=mult_all, block_size=W["block"], d_sum_ptr=da[first].data_ptr(),
+            eng.run_batch(mult=mult_alt if variant else mult_all, block_size=W["block"], d_sum_ptr=da[first].data_ptr(),
                           d_cnt_ptr=dc[first].data_ptr())
+        elif variant:
+            eng.run_mult(alt_mult, alt_B, d_sum_ptr=da[0].data_ptr(), d_cnt_ptr=dc[0].data_ptr())
         else:
             eng.run_device(da[0].data_ptr(), dc[0].data_ptr())
         if record:
             record_timing()
+        region = "serial" if mode["serial"] else "pipelined"
+        cnt_job = cnt_flat_alt if (variant and not batched) else cnt_flat
         if world == 1:
             # results leave the device in chunks of matrices (the engine call has synchronised its stream); the host
             # tail (ngd_finish) of one chunk runs while the next is in flight -- on the worker thread, so that this
@@ -313,15 +350,17 @@ def main():
                     evs[c].record(copy_stream)
 
             def tail():
-                cnts = h_call1.numpy().view(np.uint64) if pdel else cnt_flat
+                cnts = h_call1.numpy().view(np.uint64) if pdel else cnt_job
                 with np.errstate(all="ignore"):
                     for c, (a, b) in enumerate(chunks):
                         evs[c].synchronize()
                         N.finish(ha[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], 0, W["evol_model"],
                                  out=dist_all[a:b].reshape(-1))
                 last["dist"] = dist_all[-1]
+                if args.vary_jobs:
+                    sums_seen[region].append(checksum(dist_all))
 
-            if serial_tail:
+            if mode["serial"]:
                 tail()
             else:
                 tail_job[buf] = tail_pool.submit(tail)
@@ -345,7 +384,7 @@ def main():
                 if pdel:
                     h_cflat.copy_(dcf)
                     scatter_sum(h_cflat, h_cmine)
-            cnts = h_cmine.numpy().view(np.uint64)[:c_hi - c_lo] if pdel else cnt_flat[c_lo:c_hi]
+            cnts = h_cmine.numpy().view(np.uint64)[:c_hi - c_lo] if pdel else cnt_job[c_lo:c_hi]
             with np.errstate(all="ignore"):
                 N.finish(h_mine.numpy()[:c_hi - c_lo], cnts, 0, W["evol_model"],
                          out=h_dist_mine.numpy()[:c_hi - c_lo])
@@ -358,8 +397,10 @@ def main():
             else:
                 gather_cells(h_dist_all, h_dist_mine)
             last["dist"] = h_dist_all.numpy()[:total].reshape(n_mat, n_pairs)[-1]
+            if args.vary_jobs and rank == 0:
+                sums_seen[region].append(checksum(h_dist_all.numpy()[:total]))
 
-        if serial_tail:
+        if mode["serial"]:
             tail_n()
         else:
             tail_job[buf] = tail_pool.submit(tail_n)
@@ -389,18 +430,61 @@ def main():
                 gather_cells(d_dist_all if on_gpu else h_dist_all, d_dist_mine if on_gpu else h_dist_mine)
                 if on_gpu:
                     torch.cuda.current_stream().synchronize()
-            if serial_tail:
-                comms_up()
-            else:
+            comms_up()
+            if run_pipelined:  # the worker is the thread that issues the pipelined region's collectives
                 tail_pool.submit(comms_up).result()
+    # the shader clock while the timed kernels run: the device's own reading (pp_dpm_sclk marks the current level),
+    # polled from a thread; the main thread sits in hipStreamSynchronize (GIL released) most of the time
+    clk = {"mhz": [], "stop": False, "src": None}
+
+    def poll_clock():
+        import glob
+        files = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if not files:
+            return
+        f = files[min(local_rank, len(files) - 1)]
+        clk["src"] = f
+        while not clk["stop"]:
+            try:
+                for ln in open(f).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        clk["mhz"].append(float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+            except Exception:
+                return
+            time.sleep(0.002)
+
+    def alt(k):  # --vary_jobs: which job step k of a region computes
+        return (args.steps - 1 - k) & 1 if args.vary_jobs else 0
+
     for _ in range(args.warmup):
         step(False)
     fence()
+    import threading
+    poller = threading.Thread(target=poll_clock, daemon=True)
+    if rank == 0:
+        poller.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        step(True, alt(k))
     fence()
     dt = time.perf_counter() - t0
+    clk["stop"] = True
+    # second region: the same K jobs two deep (job k's tail beside job k+1's kernels) -- throughput of a stream of jobs,
+    # reported apart; a real run is ONE job and cannot hide its tail behind a next one
+    dt_pipe = None
+    if run_pipelined:
+        mode["serial"] = False
+        for _ in range(min(2, args.warmup)):
+            step(False)
+        fence()
+        tp = time.perf_counter()
+        for k in range(args.steps):
+            step(False, alt(k))
+        fence()
+        dt_pipe = time.perf_counter() - tp
+        mode["serial"] = True
+        if world > 1:
+            dt_pipe = allred(dt_pipe, dist.ReduceOp.MAX)
     if world > 1:
         dt = allred(dt, dist.ReduceOp.MAX)
         # per-rank accumulation-kernel time: report the slowest rank's mean
@@ -507,11 +591,12 @@ def main():
         # reports as table rounds per (tile, site) and which is fixed at its measured mean for the per-pair kernels.
         ps_launch = pair_sites_per_launch_all / world
         lane_peak = PEAK_FP64_TFLOPS * 1e12 / 2  # FP64 lane-instruction slots per second (1 slot = 1 FMA = 2 flop)
-        roof = {"bound": "mfma", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
+        roof = {"bound": "valu", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": lane_peak,
+                "unit": "lane-instructions/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
                 "pair_sites_per_s": ps_launch / t_acc,
-                "algorithmic": "FP64 vector pipe (shares the FP64 MFMA datapath and its 78.6 TFLOP/s); 1 lane-instruction "
-                               "= 1 FMA slot = 2 flop"}
+                "algorithmic": "VALU lane-instructions the kernel EXECUTES on active lanes (v_cmpx, v_add_u32 and moves "
+                               "included: not a flop count) against the FP64 vector pipe's issue rate, 39.3e12 lane slots/s "
+                               "(16 lanes per SIMD and cycle; the 78.6 TFLOP/s FP64 peak is this x 2 flop per FMA)"}
         # Work per pair-site of THIS kernel on THIS data, from the PMC pass of tools/em_pmc.sh (accepted only if it was
         # measured on the kernel source this library was built from): lanes that executed a VALU instruction
         # (SQ_THREAD_CYCLES_VALU) and issue slots taken (SQ_INSTS_VALU x 64).  `frac` is the ACTIVE-LANE figure: it cannot
@@ -523,7 +608,7 @@ def main():
             now = hashlib.sha256(open(os.path.join(ROOT, "ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
             stale = vj.get("kernel_source_sha16", {}).get(src) != now
             act, iss = vj["per_pair_site"]["active_lane_instructions"], vj["per_pair_site"]["issue_slots"]
-            roof["achieved"] = act * ps_launch / t_acc * 2 / 1e12
+            roof["achieved"] = act * ps_launch / t_acc
             roof["frac"] = roof["active_lane_frac"] = act * ps_launch / t_acc / lane_peak
             roof["issue_slot_frac"] = iss * ps_launch / t_acc / lane_peak
             roof["frac_kind"] = ("active lanes: %.1f executed lane-instructions per pair-site (SQ_THREAD_CYCLES_VALU) x pair-sites "
@@ -566,6 +651,23 @@ def main():
     except Exception:
         pass
 
+    # the dominant kernel's launches inside the timed region (HIP events on the engine's stream) and the shader clock
+    # the device reported meanwhile: what a rocprofv3 pass of this command must reproduce (tools/profile.sh keeps its
+    # kernel trace only if its own ms_per_step is within 2 % of an unprofiled line of the same lease)
+    if acc_ms:
+        roof["ms_per_launch_min"], roof["ms_per_launch_median"] = float(np.min(acc_ms)), float(np.median(acc_ms))
+        roof["launches_timed"] = len(acc_ms)
+    roof["sclk_mhz"] = ({"median": float(np.median(clk["mhz"])), "min": float(np.min(clk["mhz"])),
+                         "max": float(np.max(clk["mhz"])), "samples": len(clk["mhz"]),
+                         "source": "%s (the level marked current), polled every 2 ms during the timed region" % clk["src"]}
+                        if clk["mhz"] else None)
+    pipeline_check = None
+    if args.vary_jobs:
+        a, b = sums_seen["serial"][-args.steps:], sums_seen["pipelined"][-args.steps:]
+        pipeline_check = {"steps_compared": len(b), "jobs_differ": len(set(a)) > 1,
+                          "ok": bool(b) and a == b and len(set(a)) > 1}
+        valid = valid and (pipeline_check["ok"] or not run_pipelined)
+
     out = {
         "metric": "pair-distances/sec", "value": value, "unit": "pair-distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -578,11 +680,8 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
-                   "host_tail": ("serial: a job's copy-out and ngd_finish end before the next job's kernels start "
-                                 "(ms_per_step = one job's latency)" if serial_tail or by_reps else
-                                 "pipelined: job k's tail (copy-out and ngd_finish; N > 1: reduce-scatter, each rank's share "
-                                 "of ngd_finish, all-gather) runs on a worker thread beside job k+1's kernels; all K jobs, "
-                                 "tails included, end inside the timed region"),
+                   "host_tail": "serial: a job's copy-out and ngd_finish (N > 1: the collectives too) end before the next "
+                                "job's kernels start -- ms_per_step and value are ONE job's latency",
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "
                                 "reduce-scatter adds the sums, every rank finishes its 1/%d of the cells on its host, one "
@@ -591,8 +690,13 @@ def main():
                                 "resident on every GPU, one RCCL all-gather of the finished matrices" % (world - 1))
                                if by_reps else
                                ("pair tiles dealt over %d rank(s), input replicated" % world)},
+        "pipelined": None if dt_pipe is None else {
+            "ms_per_step": dt_pipe * 1e3 / args.steps, "value": n_pairs * n_mat * args.steps / dt_pipe,
+            "note": "a second region of the same K jobs, two in flight: job k's tail (copy-out and ngd_finish; N > 1: "
+                    "reduce-scatter, each rank's share of ngd_finish, all-gather) on a worker thread beside job k+1's "
+                    "kernels, every tail inside the region -- throughput of a stream of jobs, not the headline"},
         "roofline": roof, "cpu_baseline": cpu, "spot_check": spot, "valid": valid,
-        "device_bytes": eng.device_bytes(),
+        "pipeline_check": pipeline_check, "device_bytes": eng.device_bytes(),
         "ms_reduce": float(np.mean(red_ms)), "ms_engine_total": float(np.mean(tot_ms)),
     }
     print(json.dumps(out))

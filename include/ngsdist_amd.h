@@ -230,6 +230,12 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_BOOT_UNALIGNED 4 /* [1] MFMA path: partials also for block sizes that are not multiples of 4 sites   */
 #define NGD_OPT_EM_BATCH 5       /* [1] EM kernels without partials: up to 16 (per-pair) / 8 (table-driven) matrices  */
                                  /*     per accumulation pass                                                         */
+#define NGD_OPT_EM_SPILL 6       /* [1] table-driven EM kernel without partials, 3 matrices or more: ONE pass writes   */
+                                 /*     the per-(pair, site) terms of a chunk of sites, one FP64 MFMA contraction with  */
+                                 /*     the matrices' weights adds the chunk to every matrix (any replicate count);     */
+                                 /*     0 never, 1 from 3 matrices on, 2 from 2 on.  Matrices then agree with their own */
+                                 /*     ngd_run() pass to rounding (<= 1e-12 relative), not bit for bit                 */
+#define NGD_OPT_EM_SPILL_BYTES 7 /* [0 = 6 GB] device scratch for those terms (bounds the sites per chunk)             */
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);

@@ -356,16 +356,26 @@ constexpr int PACK_DENSE = NGD_PACK_DENSE;
 // the EM of a (pair, site) does not depend on the replicate, only its weight does).  Wb[s][RB] = the site's weight in
 // each matrix; the slab holds RB planes per slice.  The RB x 8 accumulators take the registers of a second workgroup:
 // one workgroup per CU.
-template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK, int RB>
+//
+// SPILL: the per-site terms leave the kernel instead of being summed: term (pair slot p, site k) of the chunk of sites
+// [site_base, n_sites_eff) goes to slab[((k / 4) * n_pad + p / 16) * 64 + (k % 4) * 16 + p % 16] (n_pad = pair slots /
+// 16 here; pair slot = tile * 4096 + row * 64 + column) -- the fragment-major operand layout of ngd_internal.h with
+// "individual" = pair slot, so that contract_mfma.hip contracts the chunk with any number of bootstrap weight vectors
+// by FP64 MFMA.  Terms that are not finite (an all-zero individual: 0/0 in normalize(), as on the CPU) raise the flag
+// word `nanlist`; the chunk is then sanitised before it is contracted (0 x NaN must not reach the matrices that do
+// not draw the site).
+template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK, int RB, bool SPILL = false>
 __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     const double *__restrict__ PA, const uint32_t *__restrict__ ws, const double *__restrict__ Wb, ngd_score sc,
     const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind,
     uint64_t n_sites_eff, uint64_t sites_per_slice, double *__restrict__ slab,
-    unsigned long long *__restrict__ counters) {
+    unsigned long long *__restrict__ counters, uint64_t site_base = 0,
+    unsigned long long *__restrict__ nanlist = nullptr) {
   constexpr int RPW = TS / NW;  // rows per wavefront
   constexpr int RS = em_tables<CH, PACK>::RS;
   static_assert(!PACK || NW == 8, "packed units: 8 wavefronts x 8 rows");
   static_assert(RB == 1 || (PACK && WEIGHTED), "several matrices per pass: the packed form, weighted");
+  static_assert(!SPILL || (PACK && !WEIGHTED && RB == 1), "spilled terms: the packed form, unweighted");
   // rows per group (one uniform "anything left?" test per group; their table reads are in flight together)
   constexpr int GR = (WPS >= 4 || PACK) ? 1 : 4;
   static_assert(RPW % GR == 0 && CH % 4 == 0 && (CH % 8 == 0 || CH % 8 == 4), "shape");
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   const uint32_t I0 = tiles[tile].ti * TS, J0 = tiles[tile].tj * TS;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint64_t s0 = (uint64_t)ks * sites_per_slice;
+  const uint64_t s0 = site_base + (uint64_t)ks * sites_per_slice;
   uint64_t s1 = s0 + sites_per_slice;
   if (s1 > n_sites_eff) s1 = n_sites_eff;
 
@@ -592,6 +602,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #endif
       if (*(const volatile __attribute__((address_space(3))) uint32_t *)&L.more[round & 1] == 0) { round++; break; }
     }
+    if constexpr (SPILL) {  // this site's 8 x 64 terms of the wavefront: four runs of 128 B per row
+      const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(s - site_base));
+      double *dst = slab + ((uint64_t)(k >> 2) * n_pad + (uint64_t)tile * 256 + wave * (RPW * 4)) * 64 + (k & 3) * 16;
+      const uint32_t loff = (lane >> 4) * 64 + (lane & 15);
+      bool bad = false;
+#pragma unroll
+      for (int r = 0; r < RPW; r++) {
+        const double c = acc[r][0];
+        bad = bad || !(__builtin_fabs(c) <= 1.7976931348623157e308);
+        dst[r * 256 + loff] = c;
+        acc[r][0] = 0;
+      }
+      // a term that is not finite (an all-zero individual: 0/0 in normalize(), as on the CPU): k_spill_sanitize
+      // (contract_mfma.hip) then goes over this chunk before it is contracted
+      if (bad) *(volatile unsigned long long *)nanlist = 1ull;
+    }
   }
   if (tid == 0) {  // work done, for the roofline accounting of bench.py: (tile, site) visits and table rounds
     atomicAdd(&counters[0], (unsigned long long)sites_done);
@@ -612,11 +638,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
         if ((pz >> b) & 1) acc[r][b] = __builtin_nan("");
     }
   }
+  if constexpr (!SPILL) {
 #pragma unroll
-  for (int r = 0; r < RPW; r++)
+    for (int r = 0; r < RPW; r++)
 #pragma unroll
-    for (int b = 0; b < RB; b++)
-      slab[(((uint64_t)ks * RB + b) * n_pad + (I0 + wave * RPW + r)) * n_pad + j] = acc[r][b];
+      for (int b = 0; b < RB; b++)
+        slab[(((uint64_t)ks * RB + b) * n_pad + (I0 + wave * RPW + r)) * n_pad + j] = acc[r][b];
+  }
 }
 
 }  // namespace
@@ -668,4 +696,20 @@ void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const do
     if (pairwise_del) NGD_EMTB(true, 4); else NGD_EMTB(false, 4);
   }
 #undef NGD_EMTB
+}
+
+// The terms of sites [s_lo, s_hi) of every pair slot, unsummed, into C (fragment-major, n_pg = n_tiles64 * 256 groups of
+// 16 pair slots per k-group of 4 sites; see the SPILL note at the kernel).  *d_nanflag is set to 1 if a term of the
+// chunk was not finite.
+void ngd_launch_accum_em_table_spill(hipStream_t st, const ngd_geom &g, const double *PA, uint64_t s_lo, uint64_t s_hi,
+                                     const ngd_score &score, int pairwise_del, const ngd_tile *d_tiles64,
+                                     uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, double *C,
+                                     unsigned long long *d_counters, unsigned long long *d_nanflag) {
+  if (!n_tiles64 || s_hi <= s_lo) return;
+#define NGD_EMTS(P)                                                                                                      \
+  hipLaunchKernelGGL((k_accum_em_table<8, 16, 4, false, P, true, 1, true>), dim3(n_tiles64 * n_ks), dim3(512), 0, st, PA, \
+                     nullptr, nullptr, score, d_tiles64, n_tiles64, g.n_ig, n_tiles64 * 256u, g.n_ind, s_hi,             \
+                     sites_per_slice, C, d_counters, s_lo, d_nanflag)
+  if (pairwise_del) NGD_EMTS(true); else NGD_EMTS(false);
+#undef NGD_EMTS
 }

@@ -104,6 +104,11 @@ struct ngd_engine {
   ngd_timing timing{};
   // plan options (ngd_set_option)
   uint64_t opt_boot_partials = 1, opt_boot_max_bytes = 0, opt_boot_wg = 4096, opt_boot_unaligned = 1, opt_em_batch = 1;
+  uint64_t opt_em_spill = 1, opt_em_spill_bytes = 0;
+  // EM bootstrap by spilled terms + one MFMA contraction (contract_mfma.hip): running sums and per-chunk NaN flags
+  double *d_D = nullptr;
+  unsigned long long *d_nanflag = nullptr;
+  uint64_t cap_D = 0, cap_nanflag = 0;
 };
 
 template <typename T>
@@ -165,7 +170,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -956,6 +961,107 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   return NGD_OK;
 }
 
+// EM path, many matrices, blocks too small for per-block partials: ONE pass of the table-driven EM kernel writes the
+// per-(pair, site) terms of a chunk of sites (they do not depend on the replicate), one FP64 MFMA contraction adds
+// the chunk to the running sums of every matrix of the job (contract_mfma.hip).  The chunk is as many sites as the
+// scratch budget holds (NGD_OPT_EM_SPILL_BYTES).  Outputs: [lead + n_rep][n_pairs]; every matrix agrees with its own
+// ngd_run() pass to rounding (the sums are formed in another order).  *done = false: the plan does not apply
+// (no room for a useful chunk) and nothing has been written.
+static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mult_max, const unsigned long long *drawn,
+                         uint32_t n_rep, bool lead, uint64_t n_blocks, uint64_t block_size, double *d_sum,
+                         unsigned long long *d_cnt, bool *done) {
+  const ngd_geom &g = e->g;
+  *done = false;
+  const uint64_t n_pairs = ngd_n_pairs(g.n_ind);
+  const uint64_t n_eff = n_blocks * block_size;
+  const uint32_t n_mat = n_rep + (lead ? 1u : 0u);
+  const uint32_t n_rg = ngd_contract_rep_groups(n_mat);
+  const uint64_t n_pg = (uint64_t)e->n_tiles64 * 256;  // groups of 16 pair slots
+  const uint64_t s_end = lead ? g.n_sites : n_eff;
+  if (!e->n_tiles64 || n_pg >= (1ull << 32) || !s_end) return NGD_OK;
+  const uint64_t kg_bytes = n_pg * 64 * 8;  // one k-group (4 sites) of terms
+  const uint64_t d_elems = (uint64_t)n_rg * n_pg * 256;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  const uint64_t have = e->slab_boot_elems * 8 + e->cap_D * 8;
+  // default scratch: 6 GB of terms (a device allocation costs ~12 ms per GB once; [measured] tools/em_boot_job.py)
+  uint64_t budget = e->opt_em_spill_bytes ? e->opt_em_spill_bytes : (6ull << 30);
+  if (e->opt_boot_max_bytes) budget = std::min(budget, e->opt_boot_max_bytes);
+  const uint64_t room = free_b + have > d_elems * 8 + (2ull << 30) ? free_b + have - d_elems * 8 - (2ull << 30) : 0;
+  budget = std::min(budget, room);
+  uint64_t chunk_kg = budget / kg_bytes;
+  if (chunk_kg < 2) return NGD_OK;
+  chunk_kg = std::min<uint64_t>(chunk_kg - 1, (s_end + 3) / 4);  // (one k-group of tail for the operand run-ahead)
+  // chunks of a few sites are launch-bound: the plan is left to the others (unless the caller set the scratch size)
+  if (!e->opt_em_spill_bytes && chunk_kg * 4 < std::min<uint64_t>(s_end, 64)) return NGD_OK;
+  const uint64_t chunk_sites = chunk_kg * 4;
+  const uint64_t n_chunks = (s_end + chunk_sites - 1) / chunk_sites;
+
+  e->boot_B = 0;  // the partial-sum slab is this plan's scratch
+  int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (chunk_kg + 1) * n_pg * 64);
+  if (rc) return rc;
+  rc = ensure_cap(e, &e->d_W, &e->cap_W, (chunk_kg + 1) * (uint64_t)n_rg * 64);
+  if (rc) return rc;
+  rc = ensure_cap(e, &e->d_M, &e->cap_M, std::max<uint64_t>(1, (uint64_t)n_rep * n_blocks));
+  if (rc) return rc;
+  rc = ensure_cap(e, &e->d_D, &e->cap_D, d_elems);
+  if (rc) return rc;
+  rc = ensure_cap(e, &e->d_nanflag, &e->cap_nanflag, n_chunks);
+  if (rc) return rc;
+  *done = true;
+
+  HIPCHK(hipEventRecord(e->ev[0], e->st));
+  if (n_rep) HIPCHK(hipMemcpyAsync(e->d_M, mult, (uint64_t)n_rep * n_blocks * 4, hipMemcpyHostToDevice, e->st));
+  HIPCHK(hipMemsetAsync(e->d_D, 0, d_elems * 8, e->st));
+  HIPCHK(hipMemsetAsync(e->d_nanflag, 0, n_chunks * 8, e->st));
+  if (e->cfg.shard_world > 1) HIPCHK(hipMemsetAsync(d_sum, 0, (uint64_t)n_mat * n_pairs * sizeof(double), e->st));
+  if (e->cfg.shard_world > 1 || e->cfg.pairwise_del)  // k_count adds with integer atomics
+    HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_mat * n_pairs * sizeof(unsigned long long), e->st));
+  HIPCHK(hipEventRecord(e->ev[1], e->st));
+  double *C = e->slab_boot;
+  for (uint64_t c = 0; c < n_chunks; c++) {
+    const uint64_t s_lo = c * chunk_sites, s_hi = std::min(s_end, s_lo + chunk_sites);
+    const uint64_t len = s_hi - s_lo, n_kg = (len + 3) / 4;
+    if (len & 3) HIPCHK(hipMemsetAsync(C + (n_kg - 1) * n_pg * 64, 0, kg_bytes, e->st));  // the last k-group is partial
+    ngd_launch_spill_weights(e->st, e->d_M, n_mat, lead ? 1 : 0, s_lo, s_hi, g.n_sites, n_eff, n_blocks, block_size, e->d_W);
+    // slices of the chunk's sites: enough workgroups to fill the device a few times over, a few sites each at least
+    uint64_t ks = std::max<uint64_t>(1, std::min<uint64_t>((8192 + e->n_tiles64 - 1) / e->n_tiles64, len / 8));
+    const uint64_t sps = (len + ks - 1) / ks;
+    ks = (len + sps - 1) / sps;
+    ngd_launch_accum_em_table_spill(e->st, g, e->PA, s_lo, s_hi, e->sc, e->cfg.pairwise_del, e->d_tiles64, e->n_tiles64,
+                                    (uint32_t)ks, sps, C, e->d_emcnt, e->d_nanflag + c);
+    ngd_launch_spill_sanitize(e->st, C, e->d_nanflag + c, n_kg, (uint32_t)n_pg, e->d_M, n_mat, lead ? 1 : 0, s_lo,
+                              g.n_sites, n_eff, n_blocks, block_size, e->d_D);
+    ngd_launch_contract(e->st, e->d_W, C, n_mat, (uint32_t)n_pg, (uint32_t)n_kg, e->d_D);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(e->ev[2], e->st));
+  ngd_launch_spill_scatter(e->st, e->d_D, (uint32_t)n_pg, e->d_tiles64, e->n_tiles64, g.n_ind, n_mat, d_sum);
+  HIPCHK(hipEventRecord(e->ev[3], e->st));
+  for (uint32_t r = 0; r < n_mat; r++) {
+    unsigned long long *cnt_r = d_cnt + (uint64_t)r * n_pairs;
+    const bool is_lead = lead && r == 0;
+    const uint32_t q = r - (lead ? 1u : 0u);
+    if (!e->cfg.pairwise_del) {
+      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[q], nullptr, 1, cnt_r);
+    } else if (is_lead) {
+      ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles, e->n_tiles, cnt_r);
+    } else {
+      uint32_t n_planes = 0;
+      while (n_planes < 32 && (mult_max[q] >> n_planes)) n_planes++;
+      if (!n_planes) n_planes = 1;  // (as in pass_impl: a replicate that drew none of these blocks counts 0 sites)
+      ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)q * n_blocks, e->d_ws, nullptr);
+      ngd_launch_planes(e->st, e->d_ws, g.n_sites, g.n_words, n_planes, e->planes);
+      ngd_launch_count(e->st, g, e->mask, e->planes, n_planes, e->d_tiles, e->n_tiles, cnt_r);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev[4], e->st));
+  HIPCHK(hipStreamSynchronize(e->st));  // `mult` is the caller's host memory
+  read_timing(e, s_end, 1, false);
+  return NGD_OK;
+}
+
 // The replicate loop: optionally the full data set (matrix 0, lead_full), then n_rep bootstrap replicates given
 // as block maps (multiplicities are counted from them) or directly as multiplicities.  Outputs are
 // [lead_full + n_rep][n_pairs].  The plan is the cheapest that applies: per-block partials (one pass, then a
@@ -1036,6 +1142,16 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   //    CU and costs ~1.7 plain passes: from three matrices on it beats a plain pass + a weighted pass per replicate
   //    (0.63 of a pass each: they walk only the sites a replicate drew).  Its other shapes borrow the per-pair batch
   //    kernel from three replicates on (those agree with ngd_run()'s to rounding only).
+  // 2a. the table-driven kernel, three matrices or more: the terms of a chunk of sites are spilled once and
+  //     contracted with every matrix's weights by MFMA -- one EM pass for the whole job, whatever the replicate count
+  if (e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0 && e->opt_em_spill &&
+      n_rep + lead >= (e->opt_em_spill == 2 ? 2u : 3u)) {
+    bool done = false;
+    rc = em_spill_impl(e, mult, mult_max.data() + lead, drawn.data() + lead, n_rep, lead != 0, n_blocks, block_size,
+                       d_sum, d_cnt, &done);
+    if (rc == NGD_E_NOMEM) { (void)hipGetLastError(); g_err.clear(); done = false; rc = NGD_OK; }
+    if (rc || done) return rc;
+  }
   const bool em_pair = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
   const bool em_table_batch = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0 && n_rep + lead >= 3;
   const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape != 0 && n_rep >= 3;
@@ -1186,6 +1302,11 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       break;
     case NGD_OPT_BOOT_UNALIGNED: e->opt_boot_unaligned = value != 0; break;
     case NGD_OPT_EM_BATCH: e->opt_em_batch = value != 0; break;
+    case NGD_OPT_EM_SPILL:
+      if (value > 2) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_EM_SPILL is 0, 1 or 2");
+      e->opt_em_spill = value;
+      break;
+    case NGD_OPT_EM_SPILL_BYTES: e->opt_em_spill_bytes = value; break;
     default: return fail(NGD_E_INVALID, "ngd_set_option: unknown option");
   }
   return NGD_OK;

@@ -341,8 +341,11 @@ def test_bench_line_contract(tmp_path):
 
 
 def test_bench_pipelined_tail_and_em_roofline_fields(tmp_path):
-    """N = 1: a job's copy-out and host tail on the worker thread beside the next job's kernels (forced here on a small
-    job: --pipelined_tail) gives the same line as --serial_tail, a bootstrap job included; the EM line carries the
+    """N = 1: the headline region runs one job at a time (ms_per_step = one job's latency); a second region runs the same
+    jobs two deep -- a job's copy-out and host tail on the worker thread beside the next job's kernels (forced here on
+    small jobs: --pipelined_tail) -- and is reported apart as `pipelined`.  With --vary_jobs odd and even steps compute
+    different jobs and every tail records a checksum of its whole result: the pipelined region must reproduce the serial
+    region's checksums step by step, so a mix-up of the two buffer sets cannot pass.  The EM line carries the
     active-lane and issue-slot figures (or says why not) and the reference-em2 CPU baseline."""
     import json
     import sys
@@ -354,13 +357,16 @@ def test_bench_pipelined_tail_and_em_roofline_fields(tmp_path):
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
 
     for extra in (["--workload", "cfg2", "--n_sites", "20000"], ["--workload", "cfg5", "--n_sites", "20000"]):
-        a = line(*extra, "--no_cpu", "--pipelined_tail")
+        a = line(*extra, "--no_cpu", "--pipelined_tail", "--vary_jobs")
         b = line(*extra, "--no_cpu", "--serial_tail")
-        assert a["valid"] and b["valid"] and a["config"]["host_tail"].startswith("pipelined")
-        assert b["config"]["host_tail"].startswith("serial")
+        assert a["valid"] and b["valid"] and a["config"]["host_tail"].startswith("serial")
+        assert a["pipelined"] is not None and a["pipelined"]["ms_per_step"] > 0 and b["pipelined"] is None
+        assert a["pipeline_check"] == {"steps_compared": 5, "jobs_differ": True, "ok": True}
         assert a["spot_check"]["max_rel_err_vs_oracle"] == b["spot_check"]["max_rel_err_vs_oracle"]
+        assert a["roofline"]["launches_timed"] >= 5 and a["roofline"]["ms_per_launch_min"] <= a["roofline"]["ms_per_launch_median"]
     d = line("--workload", "cfg4", "--n_sites", "3000", "--cpu_sites", "60")
     assert d["valid"] and d["roofline"]["kernel"] == "k_accum_em_table" and "frac_kind" in d["roofline"]
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["unit"] == "lane-instructions/s"
     if d["roofline"]["frac"] is not None:
         assert d["roofline"]["frac"] == d["roofline"]["active_lane_frac"] <= d["roofline"]["issue_slot_frac"]
     ref = d["cpu_baseline"]["reference_em2"]

@@ -50,12 +50,15 @@ def test_two_ranks_em_path_reduced_sites():
 
 
 def test_two_ranks_with_the_tail_on_the_worker_thread():
-    # --pipelined_tail at N > 1: reduce-scatter, each rank's share of ngd_finish and the all-gather on the worker thread
-    # beside the next job's kernels (default at N = 1; opt-in here until it has run over RCCL)
+    # --pipelined_tail at N > 1: a second region with the reduce-scatter, each rank's share of ngd_finish and the
+    # all-gather on the worker thread beside the next job's kernels (reported apart; opt-in here until it has run over
+    # RCCL).  --vary_jobs: odd and even steps compute different jobs and the region must reproduce the serial
+    # region's per-step checksums of the gathered result (no mix-up of the two buffer sets).
     for w in (["--workload", "cfg3", "--n_sites", "100000"], ["--workload", "cfg5", "--n_sites", "50000"]):
-        out = _bench(*w, "--pipelined_tail")
-        assert out["valid"] is True and out["config"]["host_tail"].startswith("pipelined")
-        assert _bench(*w)["config"]["host_tail"].startswith("serial")
+        out = _bench(*w, "--pipelined_tail", "--vary_jobs")
+        assert out["valid"] is True and out["pipelined"]["ms_per_step"] > 0
+        assert out["pipeline_check"]["ok"] is True and out["pipeline_check"]["jobs_differ"] is True
+        assert _bench(*w)["pipelined"] is None
 
 
 def test_two_ranks_pairwise_del_counts_are_reduced():

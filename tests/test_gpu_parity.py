@@ -281,48 +281,90 @@ def test_bootstrap_batch_called_genotypes_bit_exact():
         assert np.array_equal(S[r], so) and np.array_equal(Cn[r], co)
 
 
-@pytest.mark.parametrize("kernel,block_size,pdel,partials", [
-    ("mfma", 8, True, True), ("mfma", 7, False, True), ("mfma", 1, True, True), ("stream", 3, False, True),
-    ("em_fast", 5, True, True), ("em_fast", 1, True, False), ("em_fast", 7, False, False),
-    ("em_faithful", 3, True, False), ("em_faithful", 12, False, True),
-    ("em_table", 5, True, True), ("em_table", 1, True, False), ("em_table", 7, False, False)])
+@pytest.mark.parametrize("kernel,block_size,pdel,partials,spill", [
+    ("mfma", 8, True, True, 1), ("mfma", 7, False, True, 1), ("mfma", 1, True, True, 1), ("stream", 3, False, True, 1),
+    ("em_fast", 5, True, True, 1), ("em_fast", 1, True, False, 1), ("em_fast", 7, False, False, 1),
+    ("em_faithful", 3, True, False, 1), ("em_faithful", 12, False, True, 1),
+    ("em_table", 5, True, True, 1), ("em_table", 1, True, False, 0), ("em_table", 7, False, False, 0),
+    ("em_table", 1, True, False, 1), ("em_table", 7, False, False, 1)])
 @pytest.mark.parametrize("n_rep", [0, 1, 5, 20])
-def test_whole_job_in_one_call(kernel, block_size, pdel, partials, n_rep):
+def test_whole_job_in_one_call(kernel, block_size, pdel, partials, spill, n_rep):
     """ngd_run_job: matrix 0 = ngd_run(NULL) (counts exact, sums to rounding; bit-identical where the plan keeps the
     plain pass), replicates bit-identical to ngd_run(block_map); whatever plan the engine picks: per-block partials
     with the all-ones row (mfma 8 / em with partials on), the EM batch pass (partials off: what large data sets with
     small blocks get; 16 matrices per pass in the per-pair kernels, 8 in the table-driven one), one list-driven
-    weighted pass per replicate (mfma 7, 1), the streaming kernel."""
+    weighted pass per replicate (mfma 7, 1), the streaming kernel.  The table-driven EM kernel without partials, three
+    matrices or more (spill = 1, the default): the terms are spilled once and contracted with every matrix's weights
+    (contract_mfma.hip) -- every matrix then agrees with its own pass to rounding, not bit for bit."""
     n_ind, n_sites = 21, 1203
+    spilled = kernel == "em_table" and not partials and spill and n_rep + 1 >= 3
     indep = kernel in INDEP_KERNELS
     p = O.synth_indmajor(31, n_ind, n_sites, miss_frac=0.2)
     rng = N().Taus(5)
     n_eff = n_sites - n_sites % block_size
     maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)]) if n_rep else None
     with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
-        e.set_option("boot_partials", 1 if partials else 0)
+        e.set_option("boot_partials", 1 if partials else 0).set_option("em_spill", spill)
         e.upload_ind_major(p).commit()
         S, Cn = e.run_job(maps, block_size)
         assert S.shape == (n_rep + 1, e.n_pairs)
         s0, c0 = e.run()
         assert np.array_equal(Cn[0], c0) and rel_err(S[0], s0) < 1e-12
-        # every plan, the table-driven EM kernel's 8-matrices-per-pass form included, gives a replicate the bits
-        # of its own one-replicate pass
+        # every plan but the spilled-terms one (the table-driven EM kernel's 8-matrices-per-pass form included) gives
+        # a replicate the bits of its own one-replicate pass
         for r in range(n_rep):
             s1, c1 = e.run(maps[r], block_size)
             assert np.array_equal(Cn[r + 1], c1)
-            assert np.array_equal(S[r + 1], s1)
-        if kernel == "em_table" and not partials and n_rep >= 2:  # the full-data matrix rides along with weight 1
+            assert rel_err(S[r + 1], s1) < 1e-12 if spilled else np.array_equal(S[r + 1], s1)
+        if kernel == "em_table" and not partials and n_rep >= 2 and not spilled:  # the full-data matrix rides along with weight 1
             assert np.array_equal(S[0], s0)
         if n_rep:  # and a batch without the leading matrix
             S2, C2 = e.run_batch(maps, block_size)
-            assert np.array_equal(S2, S[1:]) and np.array_equal(C2, Cn[1:])
+            assert np.array_equal(C2, Cn[1:])
+            assert rel_err(S2, S[1:]) < 1e-12 if spilled else np.array_equal(S2, S[1:])
     so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=indep, n_threads=8)
     assert np.array_equal(Cn[0], co) and rel_err(S[0], so) < RTOL
     if n_rep:
         so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=indep, site_src=O.boot_site_src(maps[-1], block_size),
                              n_sites=n_eff, n_threads=8)
         assert np.array_equal(Cn[-1], co) and rel_err(S[-1], so) < RTOL
+
+
+@pytest.mark.parametrize("n_ind,n_sites,block_size,n_rep,lead,pdel,scratch_kg", [
+    (37, 1501, 1, 5, True, False, 0), (37, 1501, 1, 20, True, True, 7), (70, 803, 3, 40, False, False, 33),
+    (21, 1203, 7, 131, True, False, 100), (130, 517, 1, 17, True, True, 64), (9, 40, 10, 3, False, True, 2)])
+def test_em_bootstrap_by_spilled_terms_and_one_contraction(n_ind, n_sites, block_size, n_rep, lead, pdel, scratch_kg):
+    """EM path, blocks too small for per-block partials (the reference's defaults: parse_args.cpp:29-31): ONE pass of
+    the table-driven kernel spills the per-(pair, site) terms chunk by chunk, one FP64 MFMA contraction per chunk adds
+    them to every matrix of the job (contract_mfma.hip).  Every matrix <= 1e-12 from its own ngd_run() pass, counts
+    exact, first and last matrix against the oracle; chunk sizes down to two k-groups (a partial last k-group, many
+    chunks), 3 to 132 matrices (one group of 16, several, more than one batch of 128), sites beyond the last whole
+    block (visited by the full-data matrix only)."""
+    p = O.synth_indmajor(77, n_ind, n_sites, miss_frac=0.15)
+    rng = N().Taus(3)
+    n_eff = n_sites - n_sites % block_size
+    maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)])
+    with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=False, kernel="em_table") as e:
+        e.set_option("boot_partials", 0)
+        if scratch_kg:  # scratch for that many k-groups (4 sites each) of terms
+            n_tiles64 = sum(1 for a in range((n_ind + 63) // 64) for b in range(a, (n_ind + 63) // 64))
+            e.set_option("em_spill_bytes", (scratch_kg + 1) * n_tiles64 * 256 * 64 * 8)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, block_size) if lead else e.run_batch(maps, block_size)
+        e.set_option("em_spill", 0)
+        S_b, C_b = e.run_job(maps, block_size) if lead else e.run_batch(maps, block_size)  # 8 matrices per pass
+        assert np.array_equal(Cn, C_b) and rel_err(S, S_b) < 1e-12
+        for r in sorted({0, 1, n_rep // 2, n_rep - 1}):
+            s1, c1 = e.run(maps[r], block_size)
+            assert np.array_equal(Cn[r + lead], c1) and rel_err(S[r + lead], s1) < 1e-12
+        if lead:
+            s0, c0 = e.run()
+            assert np.array_equal(Cn[0], c0) and rel_err(S[0], s0) < 1e-12
+    for m in sorted({0, n_rep - 1 + lead}):
+        src = None if (lead and m == 0) else O.boot_site_src(maps[m - lead], block_size)
+        so, co = O.all_pairs(p, pairwise_del=pdel, indep_geno=False, site_src=src,
+                             n_sites=n_sites if src is None else n_eff, n_threads=8)
+        assert np.array_equal(Cn[m], co) and rel_err(S[m], so) < RTOL
 
 
 @pytest.mark.parametrize("kernel", ["em_table", "em_fast", "em_faithful"])
@@ -333,7 +375,7 @@ def test_em_batch_pass_that_does_not_fit_falls_back_to_one_pass_per_matrix(kerne
     p = O.synth_indmajor(8, n_ind, n_sites, miss_frac=0.1)
     maps = np.stack([N().Taus(9 + k).block_map(n_sites // B) for k in range(5)])
     with N().Engine(n_ind, n_sites, indep_geno=False, kernel=kernel, pairwise_del=True) as e:
-        e.set_option("boot_partials", 0)
+        e.set_option("boot_partials", 0).set_option("em_spill", 0)
         e.upload_ind_major(p).commit()
         S, Cn = e.run_job(maps, B)
         e.set_option("boot_max_bytes", 4096)
@@ -509,7 +551,7 @@ def test_all_zero_site_vectors_count_and_contribute_nothing():
             assert rel_err(s[ok], so[ok]) < RTOL
 
 
-@pytest.mark.parametrize("kernel", EM_KERNELS)
+@pytest.mark.parametrize("kernel", EM_KERNELS + ["em_table:batch"])
 @pytest.mark.parametrize("partials", [0, 1])
 def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel, partials):
     """EM path, no --pairwise_del: a (0,0,0) site makes its pairs' sums NaN (0/0 in normalize(), as on the CPU) -- in
@@ -521,8 +563,10 @@ def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel,
     t = N().Taus(11)
     maps = np.stack([t.block_map(n_sites // B) for _ in range(12)])
     assert any(2 in m for m in maps) and any(2 not in m for m in maps)
+    # em_table without partials: the spilled-terms plan (its sanitising pass); "em_table:batch": the 8-matrix pass
+    kernel, _, how = kernel.partition(":")
     with N().Engine(n_ind, n_sites, indep_geno=False, kernel=kernel) as e:
-        e.set_option("boot_partials", partials)
+        e.set_option("boot_partials", partials).set_option("em_spill", 0 if how == "batch" else 1)
         e.upload_ind_major(p).commit()
         S, Cn = e.run_job(maps, B)
         S1 = np.stack([e.run(m, B)[0] for m in maps])

@@ -27,6 +27,15 @@ for j in sorted(glob.glob(os.path.join(out, "kt.json"))):
     except Exception as exc:
         print("(no bench line: %r)\n" % exc)
 
+if os.path.exists(os.path.join(out, "reconcile.txt")):
+    print("## the traced run against an unprofiled line of the same lease (tools/reconcile.py)\n")
+    print("```\n%s```\n" % open(os.path.join(out, "reconcile.txt")).read())
+
+line = None
+try:
+    line = json.loads(open(os.path.join(out, "kt.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
 stats = glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True)
 kt_ms = {}
 if stats:
@@ -39,6 +48,14 @@ if stats:
         print("| %s | %s | %.4f | %.4f | %.4f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e6,
                                                          float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, r["Percentage"]))
     print()
+    if line and line["roofline"].get("frac") is not None:
+        r = line["roofline"]
+        for k, ms in kt_ms.items():
+            if r["kernel"] in k and "reduce" not in k:
+                print("`%s`: trace average %.4f ms against %.4f ms by HIP events inside the same run (ms_per_step %.4f) -> "
+                      "roofline.frac recomputed from the trace = %.4f (the line says %.4f)\n"
+                      % (k, ms, r["ms_per_launch"], line["ms_per_step"], r["frac"] * r["ms_per_launch"] / ms, r["frac"]))
+                break
 
 print("## --pmc passes (mean per launch; every pass is a separate run)\n")
 print("| pass | kernel | counter | launches | mean per launch |")
