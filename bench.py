@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
+    ap.add_argument("--exact_shapes", type=int, default=0,
+                    help="ngd_config.exact_shapes: the MFMA kernel's block form (0 = the engine's choice; experiments)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -119,7 +121,7 @@ def main():
     import torch.distributed as dist
 
     import ngsdist_amd as N
-    from ngsdist_amd.dist import gather_cells, gather_matrices, scatter_sum, share_of
+    from ngsdist_amd.dist import gather_cells, gather_matrices, owned_cells, scatter_sum, share_of, unpack_cells
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,10 +137,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            probe = torch.zeros(1, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(probe)  # the communicator really comes up here (lazy under RCCL): fail now, not in a step
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+        except Exception as exc:  # no JSON line, no retry in this process: the launcher sees a non-zero exit
+            sys.stderr.write("bench.py: rank %d of %d (cuda:%d, backend %s): collective initialisation failed: %r\n"
+                             % (rank, world, local_rank, args.backend, exc))
+            sys.stderr.flush()
+            os._exit(3)
 
     W = dict(WORKLOADS[args.workload])
     if args.n_sites:
@@ -155,6 +167,8 @@ def main():
     if world == 1:
         shard = "none"
     by_sites, by_reps = shard == "sites", shard == "replicates"
+    # pair tiles are disjoint: a rank finishes its own cells and ONE all-gather of finished cells ends the job
+    by_pairs = shard == "pairs" and world > 1
     pdel = args.pairwise_del
     if pdel and by_reps:
         raise SystemExit("bench.py: --pairwise_del is wired for --shard sites|pairs")
@@ -173,13 +187,14 @@ def main():
         n_units = n_eff // unit
         lo = (n_units * rank // world) * unit
         hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
-        eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel)
+        eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
+                       exact_shapes=args.exact_shapes)
         eng.synth_fill(W["seed"], args.miss_frac, site0=lo)
         blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
     else:
         lo, hi = 0, n_sites
         eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world)
+                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes)
         eng.synth_fill(W["seed"], args.miss_frac)
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
@@ -246,6 +261,19 @@ def main():
         step_no = [0]
         d_flat_b = [d_flat, torch.zeros_like(d_flat)]
         d_cflat_b = [d_cflat, torch.zeros_like(d_cflat)]
+        if by_pairs:
+            own_idx, own_cap = owned_cells(n_ind, n_mat, world)
+            n_own = len(own_idx[rank])
+            d_own_idx = torch.from_numpy(own_idx[rank]).to(dev)
+            d_own = torch.zeros(own_cap, dtype=torch.float64, device=dev)
+            h_own, h_own_dist = pin(own_cap), pin(own_cap)
+            h_own_dist.zero_()
+            d_own_cnt = torch.zeros(own_cap, dtype=torch.int64, device=dev)
+            h_own_cnt = torch.zeros(own_cap, dtype=torch.int64).pin_memory()
+            d_own_dist = torch.zeros(own_cap, dtype=torch.float64, device=dev)
+            d_gath = torch.zeros(world * own_cap, dtype=torch.float64, device=dev)
+            h_gath = pin(world * own_cap)
+            dist_full = np.zeros(total)
         if world > 1:
             d_mine = torch.empty(chunk, dtype=torch.float64, device=dev)
             h_mine, h_dist_mine = pin(chunk), pin(chunk)
@@ -370,6 +398,31 @@ def main():
         # stream: this job's sums are in d_flat_b[buf]; the next job writes the other set.)
         df, dcf = d_flat_b[buf], d_cflat_b[buf]
 
+        def tail_pairs():
+            # this rank's own cells only: pack -> D2H -> gen_dist()'s tail on this host -> H2D -> ONE all-gather
+            torch.index_select(df, 0, d_own_idx, out=d_own[:n_own])
+            h_own.copy_(d_own, non_blocking=True)
+            if pdel:
+                torch.index_select(dcf, 0, d_own_idx, out=d_own_cnt[:n_own])
+                h_own_cnt.copy_(d_own_cnt, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            cnts = h_own_cnt.numpy().view(np.uint64)[:n_own] if pdel else cnt_job[own_idx[rank]]
+            with np.errstate(all="ignore"):
+                N.finish(h_own.numpy()[:n_own], cnts, 0, W["evol_model"], out=h_own_dist.numpy()[:n_own])
+            if on_gpu:
+                d_own_dist.copy_(h_own_dist, non_blocking=True)
+                gather_cells(d_gath, d_own_dist)
+                if rank == 0:
+                    h_gath.copy_(d_gath, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            else:
+                gather_cells(h_gath, h_own_dist)
+            if rank == 0:
+                unpack_cells(h_gath.numpy().reshape(world, own_cap), own_idx, dist_full)
+                last["dist"] = dist_full.reshape(n_mat, n_pairs)[-1]
+                if args.vary_jobs:
+                    sums_seen[region].append(checksum(dist_full))
+
         def tail_n():
             if on_gpu:
                 scatter_sum(df, d_mine)
@@ -400,10 +453,11 @@ def main():
             if args.vary_jobs and rank == 0:
                 sums_seen[region].append(checksum(h_dist_all.numpy()[:total]))
 
+        the_tail = tail_pairs if by_pairs else tail_n
         if mode["serial"]:
-            tail_n()
+            the_tail()
         else:
-            tail_job[buf] = tail_pool.submit(tail_n)
+            tail_job[buf] = tail_pool.submit(the_tail)
 
     def fence():
         if not by_reps:
@@ -424,6 +478,11 @@ def main():
             gather_matrices(d_all if on_gpu else h_all, d_dist if on_gpu else h_dist)
         else:
             def comms_up():  # on the worker: it is the thread that issues the timed collectives
+                if by_pairs:
+                    gather_cells(d_gath if on_gpu else h_gath, d_own_dist if on_gpu else h_own_dist)
+                    if on_gpu:
+                        torch.cuda.current_stream().synchronize()
+                    return
                 scatter_sum(d_flat if on_gpu else h_flat, d_mine if on_gpu else h_mine)
                 if pdel:
                     scatter_sum(d_cflat if on_gpu else h_cflat, d_cmine if on_gpu else h_cmine)
@@ -689,7 +748,8 @@ def main():
                                ("one matrix per GPU (full data + %d bootstrap replicates, block size 1), data set "
                                 "resident on every GPU, one RCCL all-gather of the finished matrices" % (world - 1))
                                if by_reps else
-                               ("pair tiles dealt over %d rank(s), input replicated" % world)},
+                               ("pair tiles dealt over %d rank(s), input replicated; every rank finishes its own cells on "
+                                "its host, ONE all-gather of the finished cells" % world)},
         "pipelined": None if dt_pipe is None else {
             "ms_per_step": dt_pipe * 1e3 / args.steps, "value": n_pairs * n_mat * args.steps / dt_pipe,
             "note": "a second region of the same K jobs, two in flight: job k's tail (copy-out and ngd_finish; N > 1: "

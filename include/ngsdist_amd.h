@@ -73,8 +73,9 @@ typedef struct ngd_config {
   uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8);  */
                          /* held to what the data set allows (>= 128 k-groups / >= 1 site per slice)  */
   uint32_t wg_target;    /* workgroups wanted per launch, from which n_slices is derived when it is 0 */
-  uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 = always issue only the MFMA tiles a block   */
-                         /* needs (auto: when n_ind padded to 128 is at most 384)                      */
+  uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 / 3 = always issue only the MFMA tiles a     */
+                         /* block needs, in blocks of up to 4 x 4 / 2 x 4 tiles of 16 x 16 pairs       */
+                         /* (auto: when n_ind padded to 128 is at most 384)                            */
   uint32_t reserved[2];  /* must be zero                                                               */
 } ngd_config;
 
@@ -276,6 +277,8 @@ uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
  * the upper triangle, dealt by cost (off-diagonal tiles first) to the least loaded
  * shard -- the rule ngd_create() uses.  Pure host arithmetic. */
 uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world);
+/* the same for every pair, in pair order: owner[ngd_pair_index(n_ind, i1, i2)] (n_pairs entries) */
+void ngd_shard_map(uint64_t n_ind, uint32_t shard_world, int32_t *owner);
 /* free / total memory of a device (device < 0: the current one): lets a host decide whether a data set fits one
  * engine or has to go through it a range of sites at a time (site sharding in time instead of across GPUs) */
 int ngd_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);

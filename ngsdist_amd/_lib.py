@@ -9,7 +9,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libngsdist_amd.so")
+# NGSDIST_AMD_LIB: an A/B build of the same engine (tools/build_variant.sh) for the measuring tools; never a fallback
+LIB_PATH = os.environ.get("NGSDIST_AMD_LIB") or os.path.join(_HERE, "libngsdist_amd.so")
 
 
 class NgdConfig(C.Structure):
@@ -54,7 +55,7 @@ EXPORTS = [
     "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
     "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
-    "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair",
+    "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair", "ngd_shard_map",
 ]
 
 _lib = None
@@ -128,6 +129,8 @@ def load():
     L.ngd_pair_index.restype = u64
     L.ngd_shard_of_pair.argtypes = [u64, u64, u64, C.c_uint32]
     L.ngd_shard_of_pair.restype = C.c_uint32
+    L.ngd_shard_map.argtypes = [u64, C.c_uint32, C.POINTER(C.c_int32)]
+    L.ngd_shard_map.restype = None
     L.ngd_device_bytes.argtypes = [vp]
     L.ngd_device_bytes.restype = u64
     _lib = L

@@ -28,7 +28,7 @@
 
 namespace {
 
-constexpr int WM = 4, WN = 4;  // MFMA tiles per wavefront edge
+constexpr int WN = 4;  // MFMA tiles per wavefront edge (columns; rows: 4, or 2 in the small-job form)
 
 // DEPTH = k-groups of operands in flight per wavefront (register ring, <= NGD_KG_TAIL);
 // WPS   = wavefronts per SIMD the register budget is held to (workgroups per CU).
@@ -48,12 +48,25 @@ __device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const 
 // different shapes progress at different rates through k, which costs the L2 residency that large
 // n_ind depends on (measured: 45.5 -> 51.8 ms at n_ind = 1000) but nothing when the whole operand
 // panel of a slice is a few tens of KB.
-template <bool WEIGHTED, int DEPTH, int WPS, bool EXACT>
-__global__ __launch_bounds__(256, WPS) void k_accum_mfma(
+// EXACT = 2: the same with blocks of at most 2 x 4 tiles (8 accumulators: 6 wavefronts per SIMD instead of 3).  At a few
+// hundred individuals a slice is ~10 jobs and a launch one dispatch round: with 4 x 4 blocks a SIMD's three jobs are
+// what the dispatch order gives it (10 + 16 + 16 tiles here, 4 + 4 + 16 there), and a 16-tile job alone on the pipe
+// issues an MFMA only every 138 cycles -- the launch lasts as long as the unluckiest SIMD.  Smaller jobs, more of them
+// per SIMD: shorter critical chains, six wavefronts to cover each other's operand fetches.
+// EXACT = 3: blocks of 4 x 4 tiles like EXACT = 1, but ALL jobs of a slice in one workgroup (up to 12 wavefronts) that
+// meet at a barrier every k-group: the jobs of a slice then read the same k-group at the same time, so each operand
+// fragment leaves HBM once and serves its other readers from the CU's own L1 -- single-wavefront jobs of different
+// shapes drift apart by more than the L2 holds (one-tile jobs run four times as fast as 16-tile ones), and the launch
+// is then bound by the fabric re-delivering fragments, not by the FP64 pipe.
+// EXACT = 4: the two together -- blocks of at most 2 x 4 tiles, up to 16 of them in one workgroup in step: a SIMD's
+// four wavefronts then have MFMAs to interleave through the whole k-group (a 16-tile job beside 4-tile ones issues its
+// second half alone, at the one-wavefront rate of an MFMA every 138 cycles instead of 64).
+template <bool WEIGHTED, int DEPTH, int WPS, int EXACT>
+__global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 : 256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, uint64_t k_per_slice, uint32_t w_slice_stride,
-    double *__restrict__ slab) {
+    double *__restrict__ slab, uint32_t n_igv_touch = 0) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
   const uint32_t xcd = b & 7u, q = b >> 3;
@@ -61,7 +74,12 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const uint32_t ks = (q / n_tiles) * 8u + xcd;
   // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const ngd_job job = jobs[tile * (blockDim.x >> 6) + wave];  // 4 jobs per workgroup, or 1 (EXACT)
+  // EXACT = 3 with n_igv_touch != 0: the workgroup's last wavefront computes nothing -- it reads every operand fragment
+  // of the slice two k-groups ahead of the jobs, so that their own fetches find the lines on their way or in the cache
+  // (the jobs have no registers left for a deeper operand ring; this wavefront needs none)
+  const uint32_t n_job_waves = (blockDim.x >> 6) - (EXACT >= 3 && n_igv_touch ? 1u : 0u);
+  const bool toucher = EXACT >= 3 && n_igv_touch && (uint32_t)wave == n_job_waves;
+  const ngd_job job = toucher ? ngd_job{0, 0, 1, 1, 0, 0} : jobs[tile * n_job_waves + wave];  // 4 jobs per workgroup, or 1 (EXACT)
   if (job.rows == 0) return;  // padding entry of the job list
   const uint32_t ig0 = job.ig0, jg0 = job.jg0;
   // shape code, wave-uniform: rows | cols << 3 | tri << 6
@@ -79,6 +97,33 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     kg1 = ((uint64_t)(ks + 1) * k_per_slice + 3) >> 2;
   }
   if (kg1 > n_kg) kg1 = n_kg;
+  if (EXACT >= 3 && toucher) {  // (wave-uniform)
+    const uint64_t ks_d = (uint64_t)n_ig * 64;
+    const uint32_t lo = lane * 8;
+    double sink;
+    auto touch = [&](uint64_t kg) {
+      const double *xa = PA + kg * ks_d, *xb = QB + kg * ks_d;
+      for (uint32_t gi = 0; gi < n_igv_touch; gi++) {
+        load_frag<0>(sink, lo, xa + gi * 64);
+        load_frag<0>(sink, lo, xb + gi * 64);
+      }
+    };
+    // (plain k-group ranges only: the engine gives this form no k-group list and no per-slice weights; a slice past the
+    // end of the data -- kg0 >= kg1 -- is skipped like the jobs skip it: no barrier, and nothing read out of bounds)
+    constexpr int TD = EXACT == 4 ? DEPTH : 1;  // the jobs' own operand ring: as many barriers per trip as they execute
+    static_assert(2 * TD + 1 <= NGD_KG_TAIL, "the prefetch runs 2 * TD + 1 k-groups past the slice at most");
+    if (kg0 < kg1) touch(kg0 + TD);
+    for (uint64_t kg = kg0; kg < kg1; kg += TD) {
+#pragma unroll
+      for (int d = 0; d < TD; d++) {
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // at most 24 + 2 x 16 loads in flight (the counter holds 63)
+        touch(kg + d + TD + 1);  // (past the slice: the next slice's k-groups or the images' zeroed tail)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
+    return;
+  }
   const double *wk_s = wk;  // weight of real k-group kg: wk_s + (kg - wk_kg0) * 4
   uint64_t wk_kg0 = 0;
   if (WEIGHTED && w_slice_stride) {
@@ -86,6 +131,8 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     wk_kg0 = kg0;
   }
 
+  constexpr int WM = (EXACT == 2 || EXACT == 4) ? 2 : 4;
+  constexpr bool SYNC = EXACT >= 3;
   ngd_d4 acc[WM][WN];
 #pragma unroll
   for (int m = 0; m < WM; m++)
@@ -98,7 +145,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   const uint32_t lane_off = lane * 8;
 
   constexpr int RING = DEPTH;
-  double a[RING][WM], bq[RING][WN];
+  double a[RING][4], bq[RING][WN];  // (the small-job form uses two of the four row operands)
   double wq[RING];  // bootstrap multiplicity of this lane's k (wk[4 kg + lane/16])
 #pragma unroll
   for (int d = 0; d < RING; d++) wq[d] = 0;
@@ -149,7 +196,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
                    "+v"(bq[d][1]), "+v"(bq[d][2]), "+v"(bq[d][3]), "+v"(wq[d])
                  : "n"(LPF * (DEPTH - 1)));
   };
-  static_assert(WM == 4 && WN == 4, "the asm fetch is written for 4+4 operands");
+  static_assert(WN == 4, "the asm fetch is written for 4+4 operands");
   static_assert(DEPTH >= 1 && DEPTH <= NGD_KG_TAIL, "tail padding must cover the run-ahead");
 
   // Prologue, k loop and drain as ONE unit per MFMA pattern (full: 16 tiles, triangular: 10).  The
@@ -240,6 +287,9 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     for (uint64_t kg = kg0; kg < kg1; kg += D) {
 #pragma unroll
       for (int d = 0; d < D; d++) {
+        // every job of the slice is at this k-group (loads stay in flight); a ring trip's barriers are all executed,
+        // also past the slice's last k-group, so that every wavefront of the workgroup meets the same number
+        if (SYNC) asm volatile("s_barrier" ::: "memory");
         arrive_x(d);
         if (D == 1 || kg + d < kg1) {
           if (WEIGHTED) {
@@ -270,11 +320,13 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
   typedef integral_constant<int, 4> I4;
 
   if (kg0 < kg1) {
-    if (!EXACT) {
+    if constexpr (EXACT == 0) {
       run(I4{}, I4{}, std::false_type{});
-    } else {
+    } else if constexpr (EXACT == 1 || EXACT == 3) {
       switch (shape) {  // rows | cols << 3 | tri << 6
-        case 4 | 4 << 3: run(I4{}, I4{}, std::false_type{}); break;
+        case 4 | 4 << 3:
+          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{});
+          break;
         case 4 | 3 << 3: run_exact(I4{}, I3{}, std::false_type{}, I1{}); break;
         case 4 | 2 << 3: run_exact(I4{}, I2{}, std::false_type{}, I1{}); break;
         case 4 | 1 << 3: run_exact(I4{}, I1{}, std::false_type{}, I1{}); break;
@@ -282,7 +334,21 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
         case 3 | 3 << 3 | 1 << 6: run_exact(I3{}, I3{}, std::true_type{}, I1{}); break;
         case 2 | 2 << 3 | 1 << 6: run_exact(I2{}, I2{}, std::true_type{}, I1{}); break;
         case 1 | 1 << 3 | 1 << 6: run_exact(I1{}, I1{}, std::true_type{}, I1{}); break;
-        default: run(I4{}, I4{}, std::false_type{});  // any other shape: the full pattern is always right
+        default:  // any other shape: the full pattern is always right
+          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{});
+      }
+    } else {  // EXACT 2 / 4: blocks of at most 2 x 4 tiles (engine.hip builds no other shapes for them), DEPTH k-groups in flight
+      typedef integral_constant<int, DEPTH> ID;
+      switch (shape) {
+        case 2 | 4 << 3: run_exact(I2{}, I4{}, std::false_type{}, ID{}); break;
+        case 2 | 3 << 3: run_exact(I2{}, I3{}, std::false_type{}, ID{}); break;
+        case 2 | 2 << 3: run_exact(I2{}, I2{}, std::false_type{}, ID{}); break;
+        case 2 | 1 << 3: run_exact(I2{}, I1{}, std::false_type{}, ID{}); break;
+        case 2 | 4 << 3 | 1 << 6: run_exact(I2{}, I4{}, std::true_type{}, ID{}); break;
+        case 2 | 3 << 3 | 1 << 6: run_exact(I2{}, I3{}, std::true_type{}, ID{}); break;
+        case 2 | 2 << 3 | 1 << 6: run_exact(I2{}, I2{}, std::true_type{}, ID{}); break;
+        case 1 | 1 << 3 | 1 << 6: run_exact(I1{}, I1{}, std::true_type{}, ID{}); break;
+        default: break;
       }
     }
   }
@@ -295,7 +361,7 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
     for (int n = 0; n < WN; n++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        if (EXACT && (m >= (int)(shape & 7) || n >= (int)((shape >> 3) & 7) || ((shape >> 6) && m > n))) continue;
+        if (EXACT && (m >= (int)(shape & 7) || n >= (int)((shape >> 3) & 7) || ((shape >> 6) && m > n))) continue;  // (uniform)
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
         out[(uint64_t)i * n_pad + j] = acc[m][n][r];
@@ -306,23 +372,43 @@ __global__ __launch_bounds__(256, WPS) void k_accum_mfma(
 
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
-                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
+                           int exact_shapes /* 3: n_wg = 1 workgroup of wg_waves wavefronts per slice */, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab) {
   if (!n_wg) return;
+  // EXACT = 3: a prefetching wavefront beside the jobs where a twelfth fits and the slices are plain k-group ranges
+  uint32_t touch_igv = 0;
+  if (((exact_shapes == 3 && wg_waves <= 11) || (exact_shapes == 4 && wg_waves <= 15)) && !d_ws && !d_kgl && !k_per_slice) {
+    touch_igv = (uint32_t)((g.n_ind + 15) / 16);
+    wg_waves += 1;
+  }
   // n_ks is a multiple of 8 (see the deal in the kernel)
   // EXACT: one job per (single-wavefront) workgroup -- jobs of different shapes last differently, and a
   // wavefront that is done should not wait for three siblings before its slot is handed on
 #define NGD_MFMA(W, D, P, X)                                                                                    \
-  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
-                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab)
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X >= 3 ? 64 * wg_waves : X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
+                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv)
   // No in-wave run-ahead (DEPTH 1), 3 wavefronts per SIMD: the third wavefront covers the others' load phases.
   // Measured against a 4-deep register ring at 2 wavefronts per SIMD (56.0 vs 51.0 ms on the same job layout) and
   // against LDS-staged operand panels (tools/experiments/accum_mfma_lds.hip; profiles/r01_cfg3_mfma_*): both lose.
   // (a 2-deep ring at 3 wavefronts per SIMD needs 168+ VGPRs and spills: not built)
-  if (exact_shapes) {
-    if (d_ws) NGD_MFMA(true, 1, 3, true); else NGD_MFMA(false, 1, 3, true);
+  if (exact_shapes == 2) {  // blocks of at most 2 x 4 tiles: X2D k-groups of operands in flight per wavefront
+#if !defined(NGD_EXACT2_DEPTH)
+#define NGD_EXACT2_DEPTH 1
+#endif
+    constexpr int X2D = NGD_EXACT2_DEPTH;
+    constexpr int X2W = X2D == 1 ? 6 : X2D == 2 ? 5 : 4;  // wavefronts per SIMD the registers allow
+    if (d_ws) NGD_MFMA(true, X2D, (X2W > 5 ? 5 : X2W), 2); else NGD_MFMA(false, X2D, X2W, 2);  // (weighted: 84 registers at depth 1)
+  } else if (exact_shapes == 4) {
+#if !defined(NGD_EXACT4_DEPTH)
+#define NGD_EXACT4_DEPTH 1
+#endif
+    if (d_ws) NGD_MFMA(true, NGD_EXACT4_DEPTH, 4, 4); else NGD_MFMA(false, NGD_EXACT4_DEPTH, 4, 4);
+  } else if (exact_shapes == 3) {
+    if (d_ws) NGD_MFMA(true, 1, 3, 3); else NGD_MFMA(false, 1, 3, 3);
+  } else if (exact_shapes) {
+    if (d_ws) NGD_MFMA(true, 1, 3, 1); else NGD_MFMA(false, 1, 3, 1);
   } else {
-    if (d_ws) NGD_MFMA(true, 1, 3, false); else NGD_MFMA(false, 1, 3, false);
+    if (d_ws) NGD_MFMA(true, 1, 3, 0); else NGD_MFMA(false, 1, 3, 0);
   }
 #undef NGD_MFMA
 }

@@ -61,7 +61,8 @@ struct ngd_engine {
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
   ngd_job *d_jobs = nullptr;
   uint32_t n_wg = 0;
-  int exact_shapes = 0;  // small n_ind: one code path per block shape (accum_mfma.hip EXACT)
+  uint32_t wg_waves = 4;  // wavefronts (jobs) per workgroup of the MFMA kernel
+  int exact_shapes = 0;  // small n_ind: one code path per block shape (accum_mfma.hip EXACT): 1 = blocks of 4 x 4 tiles, 2 = 2 x 4
   uint64_t *d_pairs = nullptr;
   uint64_t n_owned_pairs = 0;
   // scratch + results
@@ -196,7 +197,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
-  if (cfg->exact_shapes > 2) return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never) or 2 (always)");
+  if (cfg->exact_shapes > 5)
+    return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
+                               "(4 x 4, a slice's jobs in one workgroup) or 5 (2 x 4, one workgroup)");
   if (cfg->variant > 4) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
   const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
   if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
@@ -295,8 +298,33 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // job list of the MFMA kernel (ngd_job, units of 16 individuals).
   std::vector<ngd_job> jobs;
   const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);  // groups that hold at least one individual
-  e->exact_shapes = cfg->exact_shapes ? cfg->exact_shapes == 2 : g.n_pad <= 384;
-  if (e->exact_shapes) {
+  // auto: up to 384 individuals only the tiles a block needs are issued (accum_mfma.hip EXACT); where a slice's jobs fit
+  // one workgroup they run in step, each operand fragment leaving HBM once: up to 13 groups of 16 individuals as 16
+  // blocks of 2 x 4 tiles, up to 16 groups as 10 blocks of 4 x 4 ([measured] 100 000 sites, ms per matrix, plain / in step:
+  // n_ind = 200: 0.356 / 0.302; 250: 0.427 / 0.387; 100: 0.143 / 0.146; engine.hip falls back where they do not fit)
+  e->exact_shapes = cfg->exact_shapes ? (cfg->exact_shapes == 1 ? 0 : (int)cfg->exact_shapes - 1)
+                                      : (g.n_pad > 384 ? 0 : n_igv <= 13 ? 4 : n_igv <= 16 ? 3 : 1);
+  if (e->exact_shapes == 2 || e->exact_shapes == 4) {
+    // strips of two row groups, cut into blocks of four column groups from the diagonal on (the first block of a strip
+    // is triangular: 7 tiles of 8); an odd last row is its diagonal tile.  Under pair-tile sharding blocks must not
+    // straddle a 128-tile (8 groups): the first block of a strip then ends at the next multiple of four.
+    const bool aligned = world > 1;
+    for (uint32_t r = 0; r < n_igv; r += 2) {
+      if (n_igv - r == 1) {
+        if (owner[ngd_tile_id(g.n_t, r / 8, r / 8)] == cfg->shard_rank) jobs.push_back({(uint16_t)r, (uint16_t)r, 1, 1, 1, 0});
+        break;
+      }
+      for (uint32_t c = r; c < n_igv;) {
+        uint32_t w = std::min(4u, n_igv - c);
+        if (aligned && c % 4) w = std::min(w, 4 - c % 4);
+        if (owner[ngd_tile_id(g.n_t, r / 8, c / 8)] == cfg->shard_rank)
+          jobs.push_back({(uint16_t)r, (uint16_t)c, 2, (uint8_t)w, (uint8_t)(c == r), 0});
+        c += w;
+      }
+    }
+    auto cost = [](const ngd_job &j) { return j.tri ? j.rows * j.cols - (j.rows > 1 ? 1 : 0) : j.rows * j.cols; };
+    std::stable_sort(jobs.begin(), jobs.end(), [&](const ngd_job &a, const ngd_job &b) { return cost(a) > cost(b); });
+  } else if (e->exact_shapes) {  // (1, or 3: the same blocks, one workgroup per slice)
     // blocks of up to 4 x 4 groups over the valid groups only; the last block row / column is narrower,
     // blocks on the diagonal are triangular.  Most expensive first, four to a workgroup.
     const uint32_t nb = (n_igv + 3) / 4;
@@ -332,7 +360,37 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     }
     for (const ngd_job &j : diag) jobs.push_back(j);
   }
-  const uint32_t jobs_per_wg = e->exact_shapes ? 1 : 4;
+  if (e->exact_shapes >= 3) {
+    // One workgroup per slice, its wavefronts in step (accum_mfma.hip EXACT = 3 / 4): wavefront w runs on SIMD w % 4, so
+    // the jobs are dealt, most expensive first, to the least loaded of four bins and wavefront w takes bin w % 4's
+    // next job.  At most 12 wavefronts of 4 x 4 blocks (3 per SIMD at that kernel's register count) or 16 of 2 x 4:
+    // else the plain exact form of the same blocks.
+    const bool small = e->exact_shapes == 4;
+    auto cost = [&](const ngd_job &j) {
+      return small ? (j.tri ? j.rows * j.cols - (j.rows > 1 ? 1 : 0) : j.rows * j.cols)
+                   : (j.tri ? j.rows * (j.rows + 1) / 2 : j.rows * j.cols);
+    };
+    std::vector<ngd_job> bin[4];
+    uint32_t load[4] = {0, 0, 0, 0};
+    for (const ngd_job &j : jobs) {
+      uint32_t b = 0;
+      for (uint32_t q = 1; q < 4; q++)
+        if (load[q] < load[b]) b = q;
+      bin[b].push_back(j);
+      load[b] += cost(j);
+    }
+    std::stable_sort(bin, bin + 4, [](const std::vector<ngd_job> &a, const std::vector<ngd_job> &b) { return a.size() > b.size(); });
+    if (jobs.empty() || bin[0].size() > (small ? 4u : 3u)) {
+      e->exact_shapes = small ? 2 : 1;
+    } else {  // (the fuller bins first: no padding wavefront before the last real one)
+      jobs.clear();
+      for (size_t d = 0; d < bin[0].size(); d++)
+        for (uint32_t b = 0; b < 4; b++)
+          if (d < bin[b].size()) jobs.push_back(bin[b][d]);
+    }
+  }
+  const uint32_t jobs_per_wg = e->exact_shapes >= 3 ? (uint32_t)jobs.size() : e->exact_shapes ? 1 : 4;
+  e->wg_waves = jobs_per_wg;
   while (jobs.size() % jobs_per_wg) jobs.push_back({0, 0, 0, 0, 0, 0});
   e->n_wg = (uint32_t)(jobs.size() / jobs_per_wg);
   if (kernel == NGD_KERNEL_STREAM && world > 1) {
@@ -403,7 +461,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (kernel == NGD_KERNEL_MFMA) {
     uint64_t want = cfg->wg_target ? cfg->wg_target : 8192;
     const uint32_t wg_per_slice = std::max(1u, e->n_wg);
-    uint64_t ks = (want * (e->exact_shapes ? 4 : 1) + wg_per_slice - 1) / wg_per_slice;  // EXACT: 1-wave workgroups
+    uint64_t ks = (want * (e->exact_shapes && e->exact_shapes < 3 ? 4 : 1) + wg_per_slice - 1) / wg_per_slice;  // EXACT: 1-wave workgroups
     uint64_t max_ks = std::max<uint64_t>(8, g.n_kg / 128);  // at least 128 k-groups per slice
     ks = std::min(ks, max_ks);
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
@@ -417,7 +475,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       hipDeviceProp_t prop;
       const uint32_t cus_per_xcd = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8
                                        ? (uint32_t)prop.multiProcessorCount / 8 : 32;
-      const double slots = (double)cus_per_xcd * (e->exact_shapes ? 12 : 3);
+      // (in-step forms: whole workgroups of wg_waves jobs + the prefetching wavefront, 20 / 12 wavefronts to a CU)
+      const uint32_t sync_wgs = e->exact_shapes >= 3
+                                    ? std::max(1u, (e->exact_shapes == 4 ? 20u : 12u) / std::min(16u, e->wg_waves + 1)) : 0;
+      const double slots = (double)cus_per_xcd * (e->exact_shapes >= 3 ? sync_wgs : e->exact_shapes == 2 ? 24 : e->exact_shapes ? 12 : 3);
       // ... plus what the slice count costs afterwards: the slab reduction reads one plane per slice ([measured] 0.8 us
       // per slice at n_ind = 1000, i.e. ~5 TB/s), against an accumulation pass at ~0.8 of the FP64 peak.  It decides
       // between slice counts that fill their rounds equally well: a 1/8 site shard of cfg 3 takes 112 slices instead
@@ -615,7 +676,7 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
       ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
-                              (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, n_ks, per_slice,
+                              (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
                               kg_lim, k_per_slice, w_stride, slab);
       break;
     case NGD_KERNEL_EM_TABLE:
@@ -750,7 +811,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     sub = e->boot_sub;
     nks = e->boot_nks;
   } else {
-    const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes ? 4 : 1))
+    const uint32_t tiles_n = mfma ? std::max(1u, e->n_wg / (e->exact_shapes && e->exact_shapes < 3 ? 4 : 1))
                                   : e->kernel == NGD_KERNEL_EM_TABLE ? e->n_tiles64 : e->n_tiles16;
     const uint64_t want = e->opt_boot_wg;
     while (!unaligned && tiles_n && (uint64_t)tiles_n * n_blocks * sub < want && unit % (sub * 2) == 0 &&

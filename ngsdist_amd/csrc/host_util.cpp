@@ -231,6 +231,16 @@ uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t sh
   return c_owner[ngd_tile_id(n_t, i1 / 128, i2 / 128)];
 }
 
+// The same for every pair at once, in the reference's pair order (ngsDist.cpp:244-245): what a host needs to pack the
+// cells it owns for the ONE all-gather of a pair-sharded job.
+void ngd_shard_map(uint64_t n_ind, uint32_t shard_world, int32_t *owner) {
+  const uint32_t n_t = (uint32_t)((n_ind + 127) / 128);
+  const std::vector<uint32_t> own = ngd_tile_owners(n_t, shard_world ? shard_world : 1);
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < n_ind; i++)
+    for (uint64_t j = i + 1; j < n_ind; j++) owner[k++] = (int32_t)own[ngd_tile_id(n_t, i / 128, j / 128)];
+}
+
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites,
                uint64_t evol_model, double *dist) {
   if (evol_model > 2) return NGD_E_MODEL;  // reference: error("... model not yet supported")

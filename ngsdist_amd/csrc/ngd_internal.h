@@ -106,7 +106,7 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
 // (not whole k-groups) and d_wk holds w_slice_stride k-groups of 0/1 weights PER SLICE (ngd_launch_slice_weights).
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_wk, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
-                           int exact_shapes, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
+                           int exact_shapes, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab);
 
 // accum_em.hip : per-site EM, one thread per pair of a 16x16 tile

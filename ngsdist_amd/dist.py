@@ -17,13 +17,31 @@ from . import _lib
 
 def shard_of_pairs(n_ind, world):
     """owner rank of every pair, in the reference's pair order"""
+    import ctypes as C
     L = _lib.load()
     out = np.empty(n_ind * (n_ind - 1) // 2, dtype=np.int32)
-    k = 0
-    for i in range(n_ind):
-        for j in range(i + 1, n_ind):
-            out[k] = L.ngd_shard_of_pair(n_ind, i, j, world)
-            k += 1
+    L.ngd_shard_map(int(n_ind), int(world), out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out
+
+
+def owned_cells(n_ind, n_mat, world):
+    """Pair-tile sharding, ONE collective: (idx, cap) with idx[r] = the cells of the job ([n_mat][n_pairs], flat) that
+    rank r owns -- its pairs, matrix after matrix -- and cap = the longest of them.  Pair tiles are disjoint, so every
+    rank can finish its own cells start to finish (gen_dist()'s tail, ngsDist.cpp:372-401, on its host) and ONE
+    all-gather of `cap` finished cells per rank puts the job together: unpack_cells()."""
+    owner = shard_of_pairs(n_ind, world)
+    n_pairs = owner.size
+    idx = []
+    for r in range(world):
+        p = np.flatnonzero(owner == r).astype(np.int64)
+        idx.append((p[None, :] + n_pairs * np.arange(n_mat, dtype=np.int64)[:, None]).reshape(-1))
+    return idx, max(1, max(len(x) for x in idx))
+
+
+def unpack_cells(all_cells, idx, out):
+    """all_cells: [world][cap] as the all-gather left them (numpy); out[idx[r]] = rank r's finished cells"""
+    for r, ix in enumerate(idx):
+        out[ix] = all_cells[r, :len(ix)]
     return out
 
 

@@ -103,6 +103,59 @@ def test_two_rank_site_shards_add_up_exactly():
     assert ok_s and ok_c
 
 
+def _pair_worker(rank, world, port, n_ind, n_sites, n_mat, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import ngsdist_amd as N
+    from ngsdist_amd.dist import gather_cells, owned_cells, unpack_cells
+    from oracle import oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = O.synth_indmajor(17, n_ind, n_sites, miss_frac=0.1)
+    maps = [None] + [N.Taus(5 + r).block_map(n_sites // 4) for r in range(n_mat - 1)]
+    S, Cn = [], []
+    for m in maps:  # stand-in for the device kernels: every cell of the job
+        s, c = O.all_pairs(p, pairwise_del=True, site_src=None if m is None else O.boot_site_src(m, 4),
+                           n_sites=n_sites if m is None else n_sites // 4 * 4)
+        S.append(s), Cn.append(c)
+    S, Cn = np.stack(S).reshape(-1), np.stack(Cn).reshape(-1)
+    idx, cap = owned_cells(n_ind, n_mat, world)
+    # this rank finishes ITS cells only (pair tiles are disjoint), then ONE all-gather of finished cells
+    mine = torch.zeros(cap, dtype=torch.float64)
+    with np.errstate(all="ignore"):
+        mine[:len(idx[rank])] = torch.from_numpy(N.finish(S[idx[rank]], Cn[idx[rank]], 0, 2))
+    everyone = torch.zeros(world * cap, dtype=torch.float64)
+    gather_cells(everyone, mine)
+    if rank == 0:
+        out = unpack_cells(everyone.numpy().reshape(world, cap), idx, np.full(S.size, -7.0))
+        with np.errstate(all="ignore"):
+            want = N.finish(S, Cn, 0, 2)
+        q.put((bool(np.array_equal(out.view(np.uint64), want.view(np.uint64))), [len(x) for x in idx], cap))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pair_shards_one_all_gather_of_finished_cells():
+    """--shard pairs: every rank runs gen_dist()'s tail (ngsDist.cpp:372-401) on the cells of ITS pair tiles and one
+    all-gather of the finished cells ends the job (ngsdist_amd.dist.owned_cells / unpack_cells, what bench.py does over
+    RCCL) -- every cell of a 3-matrix job bit-identical to finishing the whole job in one process."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, 300, 64, 3, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    same, lens, cap = q.get(timeout=10)
+    assert same and all(n > 0 for n in lens) and cap == max(lens) and sum(lens) == 3 * (300 * 299 // 2)
+
+
 def test_shard_owner_covers_every_pair_once():
     os.environ.setdefault("NGD_NO_TORCH", "1")
     from ngsdist_amd.dist import shard_of_pairs

@@ -423,6 +423,40 @@ def test_shards_partition_the_pairs(kernel):
     assert np.array_equal(tot_c, co) and rel_err(tot_s, so) < RTOL
 
 
+@pytest.mark.parametrize("n_ind", [17, 33, 130, 200, 383, 600])
+@pytest.mark.parametrize("form", [2, 3, 4, 5])
+def test_mfma_exact_block_forms(n_ind, form):
+    """exact_shapes 2 / 3 / 4 (accum_mfma.hip EXACT): only the MFMA tiles a block needs, in blocks of up to 4 x 4, 2 x 4, or 4 x 4 with a slice's jobs in one workgroup (up to 12 jobs; else form 2):
+    tiles of 16 x 16 pairs -- every pair against the oracle; called genotypes bit for bit; a bootstrap replicate as a
+    weighted pass, from per-block partials with blocks of 8 sites and with blocks of 6 (masked slices); pair-tile
+    shards that partition the pairs (blocks must not straddle a 128-tile)."""
+    n_sites = 1030
+    p = O.synth_indmajor(41 + n_ind, n_ind, n_sites, miss_frac=0.1)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", exact_shapes=form) as e:
+        e.upload_ind_major(p).commit()
+        s, c = e.run()
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        for B, partials in ((8, 1), (6, 1), (5, 0)):
+            m = N().Taus(B).block_map(n_sites // B)
+            e.set_option("boot_partials", partials)
+            s1, c1 = e.run(m, B)
+            sb, cb = O.all_pairs(p, pairwise_del=True, site_src=O.boot_site_src(m, B), n_sites=n_sites // B * B, n_threads=8)
+            assert np.array_equal(c1, cb) and rel_err(s1, sb) < RTOL, (B, partials)
+    rng = np.random.default_rng(n_ind)
+    g = rng.integers(0, 3, size=(n_ind, 300))
+    pc = np.zeros((n_ind, 300, 3))
+    np.put_along_axis(pc, g[..., None], 1.0, axis=2)
+    sc, cc = O.all_pairs(pc, n_threads=8)
+    tot_s, owned = np.zeros_like(sc), np.zeros(sc.size, dtype=np.int32)
+    for r in range(3):
+        with N().Engine(n_ind, 300, kernel="mfma", exact_shapes=form, shard_rank=r, shard_world=3) as e:
+            s, c = e.upload_ind_major(pc).commit().run()
+        owned += (c > 0)
+        tot_s += s
+    assert np.all(owned == 1) and np.array_equal(tot_s, sc)
+
+
 @pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
 def test_deterministic_run_to_run(kernel):
     """results must not depend on the run (slabs summed in fixed order, no floating-point atomics) --
