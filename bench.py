@@ -236,10 +236,18 @@ def main():
         # the job's cells, flat: [n_mat][n_pairs], padded to `world` equal shares
         total = n_mat * n_pairs
         chunk, c_lo, c_hi = share_of(total, rank, world)
-        d_flat = torch.zeros(world * chunk, dtype=torch.float64, device=dev)  # the engine's (partial) sums
+        # A small single-GPU job (cfg 2: 19 900 cells) has its results written straight into pinned host memory, which
+        # HIP maps into the device's address space: the reduction kernel's stores cross PCIe while it runs (160 KB), and
+        # the separate device-to-host copy (one more launch and one more wait per 0.3 ms job) is gone.
+        zero_copy = world == 1 and total * 8 <= (1 << 20) and not pdel
+        if zero_copy:
+            d_flat = torch.zeros(world * chunk, dtype=torch.float64).pin_memory()
+            d_cflat = torch.zeros(world * chunk, dtype=torch.int64).pin_memory()
+        else:
+            d_flat = torch.zeros(world * chunk, dtype=torch.float64, device=dev)  # the engine's (partial) sums
+            # the engine's valid-site counts (ngsDist.cpp:362): per rank its own sites' / its own pairs' share
+            d_cflat = torch.zeros(world * chunk, dtype=torch.int64, device=dev)
         d_all_1 = d_flat[:total].view(n_mat, n_pairs)
-        # the engine's valid-site counts (ngsDist.cpp:362): per rank its own sites' / its own pairs' share
-        d_cflat = torch.zeros(world * chunk, dtype=torch.int64, device=dev)
         d_call_1 = d_cflat[:total].view(n_mat, n_pairs)
         # without --pairwise_del a cell's count is the number of sites its matrix visits: no exchange needed
         cnt_flat = np.full((n_mat, n_pairs), n_eff, dtype=np.uint64)
@@ -259,8 +267,8 @@ def main():
         tail_pool = concurrent.futures.ThreadPoolExecutor(1, initializer=lambda: torch.cuda.set_device(local_rank))
         tail_job = [None, None]
         step_no = [0]
-        d_flat_b = [d_flat, torch.zeros_like(d_flat)]
-        d_cflat_b = [d_cflat, torch.zeros_like(d_cflat)]
+        d_flat_b = [d_flat, torch.zeros_like(d_flat).pin_memory() if zero_copy else torch.zeros_like(d_flat)]
+        d_cflat_b = [d_cflat, torch.zeros_like(d_cflat).pin_memory() if zero_copy else torch.zeros_like(d_cflat)]
         if by_pairs:
             own_idx, own_cap = owned_cells(n_ind, n_mat, world)
             n_own = len(own_idx[rank])
@@ -369,19 +377,21 @@ def main():
             # results leave the device in chunks of matrices (the engine call has synchronised its stream); the host
             # tail (ngd_finish) of one chunk runs while the next is in flight -- on the worker thread, so that this
             # thread can hand the GPU the next job meanwhile
-            ha, h_call1, evs = h_all_b[buf], h_call_b[buf], chunk_ev[buf]
-            with torch.cuda.stream(copy_stream):
-                if pdel:
-                    h_call1.copy_(d_cflat_b[buf][:total], non_blocking=True)
-                for c, (a, b) in enumerate(chunks):
-                    ha[a:b].copy_(da[a:b], non_blocking=True)
-                    evs[c].record(copy_stream)
+            ha, h_call1, evs = (da if zero_copy else h_all_b[buf]), h_call_b[buf], chunk_ev[buf]
+            if not zero_copy:
+                with torch.cuda.stream(copy_stream):
+                    if pdel:
+                        h_call1.copy_(d_cflat_b[buf][:total], non_blocking=True)
+                    for c, (a, b) in enumerate(chunks):
+                        ha[a:b].copy_(da[a:b], non_blocking=True)
+                        evs[c].record(copy_stream)
 
             def tail():
                 cnts = h_call1.numpy().view(np.uint64) if pdel else cnt_job
                 with np.errstate(all="ignore"):
                     for c, (a, b) in enumerate(chunks):
-                        evs[c].synchronize()
+                        if not zero_copy:
+                            evs[c].synchronize()
                         N.finish(ha[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], 0, W["evol_model"],
                                  out=dist_all[a:b].reshape(-1))
                 last["dist"] = dist_all[-1]
@@ -716,9 +726,16 @@ def main():
     if acc_ms:
         roof["ms_per_launch_min"], roof["ms_per_launch_median"] = float(np.min(acc_ms)), float(np.median(acc_ms))
         roof["launches_timed"] = len(acc_ms)
+    # the clock the dominant kernel ran at, sampled INSIDE its last launch (one wavefront reads the shader-cycle and the
+    # constant-rate counter around its work: ngd_last_shader_clock); the peaks above are quoted at 2400 MHz
+    mhz = eng.shader_clock_mhz()
+    roof["shader_clock_mhz"] = mhz if mhz > 0 else None
+    if mhz > 0 and roof.get("frac") is not None:
+        roof["frac_of_peak_at_that_clock"] = roof["frac"] * 2400.0 / mhz
     roof["sclk_mhz"] = ({"median": float(np.median(clk["mhz"])), "min": float(np.min(clk["mhz"])),
                          "max": float(np.max(clk["mhz"])), "samples": len(clk["mhz"]),
-                         "source": "%s (the level marked current), polled every 2 ms during the timed region" % clk["src"]}
+                         "source": "%s (the level marked current), polled every 2 ms during the timed region; on some boxes "
+                                   "this file reports an idle level throughout -- shader_clock_mhz is the figure to use" % clk["src"]}
                         if clk["mhz"] else None)
     pipeline_check = None
     if args.vary_jobs:
@@ -739,6 +756,9 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
+                   "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
+                               "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
+                               "device buffers, copied to pinned host memory"),
                    "host_tail": "serial: a job's copy-out and ngd_finish (N > 1: the collectives too) end before the next "
                                 "job's kernels start -- ms_per_step and value are ONE job's latency",
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,

@@ -187,9 +187,15 @@ int ngd_run_mult_device(ngd_engine *e, const uint32_t *mult, uint64_t n_blocks,
  * one replicate; a replicate's result is the same whether it came from a batch or from ngd_run().
  * When the partials do not apply (streaming kernel, not enough device memory for one partial result per
  * block -- e.g. block size 1 on a large data set) this is n_rep weighted accumulation passes on the
- * --indep_geno path (each walks only the sites its replicate drew) and, on the EM path, one pass per 8
- * matrices (table-driven kernel) or 16 (per-pair kernels): the EM of a (pair, site) is computed once and
- * added to every matrix's accumulator with the site's weight there. */
+ * --indep_geno path (each walks only the sites its replicate drew).  On the EM path the term of a (pair, site)
+ * does not depend on the replicate, so the matrices share the per-site EM: the table-driven kernel (from three
+ * matrices on, NGD_OPT_EM_SPILL) writes the terms of a chunk of sites once and ONE FP64 MFMA contraction with
+ * every matrix's weights adds the chunk to all of them -- one EM pass whatever the replicate count; matrices then
+ * agree with their own ngd_run() pass to rounding (<= 1e-12 relative), counts exactly.  Otherwise (option off, two
+ * matrices, the per-pair kernels) one pass serves 8 matrices (table-driven kernel) or 16 (per-pair kernels), each
+ * accumulator taking the term with the site's weight in its matrix: same bits as from ngd_run() in the table-driven
+ * kernel's default variant and in the per-pair kernels; its other variants (1..4) borrow the per-pair batch kernel
+ * and agree with their own ngd_run() to rounding only. */
 int ngd_run_batch(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                   uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_batch_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
@@ -206,8 +212,9 @@ int ngd_run_mult_batch_device(ngd_engine *e, const uint32_t *mult, uint32_t n_re
  * matrix is the all-ones combination of the same per-block partials as the replicates; on the EM path
  * (no --indep_geno) with blocks too small for partials -- e.g. the default --boot_block_size 1 -- up to 16
  * matrices, the full-data one included, share ONE pass of the per-site EM, which does not depend on the
- * replicate.  Replicates carry the same bits as from ngd_run(); matrix 0 agrees with ngd_run(e, NULL) to
- * rounding (exactly for called genotypes) because its sum may be formed in a different order.
+ * replicate.  Replicates carry the same bits as from ngd_run() (to rounding where ngd_run_batch says so: the
+ * spilled-terms plan of the table-driven EM kernel); matrix 0 agrees with ngd_run(e, NULL) to rounding (exactly for
+ * called genotypes) because its sum may be formed in a different order.
  * n_rep = 0 is ngd_run(e, NULL, ...). */
 int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                 uint64_t block_size, double *sum, uint64_t *cnt);
@@ -240,6 +247,10 @@ int ngd_drop_caches(ngd_engine *e);
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
+/* The shader clock (MHz) the last MFMA / table-driven EM accumulation launch ran at: one wavefront in the middle of
+ * the grid reads the shader-cycle counter and the constant-rate counter around its work.  0 = not sampled (other
+ * kernels).  For roofline accounting: a kernel's rate against the peak AT THE CLOCK THE CHIP HELD. */
+int ngd_last_shader_clock(const ngd_engine *e, double *mhz);
 /* Work done by the table-driven EM kernel (NGD_KERNEL_EM_TABLE) in the last run, for roofline accounting: the number
  * of (64 x 64 pair tile, site) visits and of table rounds (16 EM steps of a tile's 128 individuals each) -- the
  * data-dependent part of its operation count (the EM's iteration count, emOptim2.cpp:118-133).  Zero for other kernels. */

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     uint64_t n_sites_eff, uint64_t sites_per_slice, double *__restrict__ slab,
     unsigned long long *__restrict__ counters, uint64_t site_base = 0,
     unsigned long long *__restrict__ nanlist = nullptr) {
+
   constexpr int RPW = TS / NW;  // rows per wavefront
   constexpr int RS = em_tables<CH, PACK>::RS;
   static_assert(!PACK || NW == 8, "packed units: 8 wavefronts x 8 rows");
@@ -385,6 +386,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   const uint32_t I0 = tiles[tile].ti * TS, J0 = tiles[tile].tj * TS;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (counters[2..3]: shader-cycle and constant-rate counter deltas around one workgroup's work, for the clock the launch
+  // ran at -- ngd_last_shader_clock(); scalar registers)
+  const bool clk_wave = blockIdx.x == (gridDim.x >> 1) && wave == 0;
+  unsigned long long clk_t0 = 0, clk_r0 = 0;
+  if (clk_wave) {
+    clk_t0 = __builtin_amdgcn_s_memtime();
+    clk_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   const uint64_t s0 = site_base + (uint64_t)ks * sites_per_slice;
   uint64_t s1 = s0 + sites_per_slice;
   if (s1 > n_sites_eff) s1 = n_sites_eff;
@@ -484,8 +493,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       // Several matrices per pass: a NaN term (an all-zero individual: 0/0 in normalize(), as on the CPU) would reach the
       // matrices that do NOT draw this site as 0 x NaN.  Such an individual is tabled like a missing one (its pairs stop
       // at once and add exactly 0) and remembered per matrix that draws the site: its pairs are set to NaN at the end.
+      // (also a sum too small for its reciprocal -- below 2^-1022 the refined rcp is inf: the one-matrix pass makes such
+      // a pair non-finite too; the prepared input of the reference sums to 1, only a raw upload can get here)
       const double a0 = (g[0] + g[1]) + g[2];
-      if (!(a0 > 0.0 && a0 <= 1.7976931348623157e308)) {
+      if (!(a0 >= 2.2250738585072014e-308 && a0 <= 1.7976931348623157e308)) {
         miss = true;
         poison |= nz;
       }
@@ -622,6 +633,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   if (tid == 0) {  // work done, for the roofline accounting of bench.py: (tile, site) visits and table rounds
     atomicAdd(&counters[0], (unsigned long long)sites_done);
     atomicAdd(&counters[1], (unsigned long long)round);
+    if (clk_wave) {
+      counters[2] = __builtin_amdgcn_s_memtime() - clk_t0;
+      counters[3] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
   }
 #if defined(NGD_EMT_STAMPS)
 #pragma unroll

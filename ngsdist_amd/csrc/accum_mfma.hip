@@ -61,12 +61,17 @@ __device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const 
 // EXACT = 4: the two together -- blocks of at most 2 x 4 tiles, up to 16 of them in one workgroup in step: a SIMD's
 // four wavefronts then have MFMAs to interleave through the whole k-group (a 16-tile job beside 4-tile ones issues its
 // second half alone, at the one-wavefront rate of an MFMA every 138 cycles instead of 64).
+// EXACT = 5: EXACT = 4's jobs with the slice's operand fragments staged through LDS: the workgroup fetches each of the
+// k-group's 2 x n_igv fragments ONCE (a wavefront takes one or two), and every job reads its six from LDS.  [measured]
+// cfg 2 (tools/exact_diag.sh): with every job fetching its own operands a k-group took 2380 cycles -- 1810 with the
+// loads taken out, 2250 with the MFMAs taken out: the ~90 fragment loads of a k-group (47 KB through one CU's vector L1)
+// bound it, not HBM (3.4 TB/s) and not the FP64 pipe (61 % busy).
 template <bool WEIGHTED, int DEPTH, int WPS, int EXACT>
-__global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 : 256, WPS) void k_accum_mfma(
+__global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 : 256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, uint64_t k_per_slice, uint32_t w_slice_stride,
-    double *__restrict__ slab, uint32_t n_igv_touch = 0) {
+    double *__restrict__ slab, uint32_t n_igv_touch = 0, unsigned long long *__restrict__ clk = nullptr) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
   const uint32_t xcd = b & 7u, q = b >> 3;
@@ -77,10 +82,19 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
   // EXACT = 3 with n_igv_touch != 0: the workgroup's last wavefront computes nothing -- it reads every operand fragment
   // of the slice two k-groups ahead of the jobs, so that their own fetches find the lines on their way or in the cache
   // (the jobs have no registers left for a deeper operand ring; this wavefront needs none)
-  const uint32_t n_job_waves = (blockDim.x >> 6) - (EXACT >= 3 && n_igv_touch ? 1u : 0u);
-  const bool toucher = EXACT >= 3 && n_igv_touch && (uint32_t)wave == n_job_waves;
+  constexpr bool TOUCH = EXACT == 3 || EXACT == 4;
+  const uint32_t n_job_waves = (blockDim.x >> 6) - (TOUCH && n_igv_touch ? 1u : 0u);
+  const bool toucher = TOUCH && n_igv_touch && (uint32_t)wave == n_job_waves;
   const ngd_job job = toucher ? ngd_job{0, 0, 1, 1, 0, 0} : jobs[tile * n_job_waves + wave];  // 4 jobs per workgroup, or 1 (EXACT)
   if (job.rows == 0) return;  // padding entry of the job list
+  // the shader clock this launch runs at: one wavefront in the middle of the grid reads the shader-cycle counter and
+  // the constant-rate one around its work (roofline accounting of bench.py; ngd_last_shader_clock())
+  const bool clk_wave = clk && b == (gridDim.x >> 1) && wave == 0;
+  unsigned long long clk_t0 = 0, clk_r0 = 0;
+  if (clk_wave) {
+    clk_t0 = __builtin_amdgcn_s_memtime();
+    clk_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   const uint32_t ig0 = job.ig0, jg0 = job.jg0;
   // shape code, wave-uniform: rows | cols << 3 | tri << 6
   const uint32_t shape = __builtin_amdgcn_readfirstlane((uint32_t)job.rows | ((uint32_t)job.cols << 3) |
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     kg1 = ((uint64_t)(ks + 1) * k_per_slice + 3) >> 2;
   }
   if (kg1 > n_kg) kg1 = n_kg;
-  if (EXACT >= 3 && toucher) {  // (wave-uniform)
+  if (TOUCH && toucher) {  // (wave-uniform)
     const uint64_t ks_d = (uint64_t)n_ig * 64;
     const uint32_t lo = lane * 8;
     double sink;
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     wk_kg0 = kg0;
   }
 
-  constexpr int WM = (EXACT == 2 || EXACT == 4) ? 2 : 4;
+  constexpr int WM = (EXACT == 2 || EXACT >= 4) ? 2 : 4;
   constexpr bool SYNC = EXACT >= 3;
   ngd_d4 acc[WM][WN];
 #pragma unroll
@@ -279,6 +293,53 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
       for (int n = 0; n < PN; n++) asm volatile("" : "+v"(bq[d][n]));
       if (WEIGHTED) asm volatile("" : "+v"(wq[d]));
     };
+    if constexpr (EXACT == 4 && D == 2) {
+      // In step, every wavefront of the workgroup is in the same phase: were the refill issued behind the MFMAs (as
+      // below), the texture path would sit idle while the MFMAs run and the MFMA pipe while the ~90 fragment loads of
+      // a k-group are processed ([measured] cfg 2: a k-group took 2400 cycles for 1470 of MFMAs, two k-groups in flight
+      // or one).  So the NEXT k-group's fetch is issued first -- into the other register set, free since the last
+      // trip -- and is processed under this k-group's MFMAs; one fetch in flight, waited for in full.
+      fetch_x(0, kidx(kg0));
+      for (uint64_t kg = kg0; kg < kg1; kg += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+#if !defined(NGD_DIAG_NOBARRIER)  // (NGD_DIAG_*: timing-only builds of tools/exact_diag.sh, results meaningless)
+          asm volatile("s_barrier" ::: "memory");
+#endif
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int m = 0; m < PM; m++) asm volatile("" : "+v"(a[d][m]));  // pins the MFMAs behind the wait
+#pragma unroll
+          for (int n = 0; n < PN; n++) asm volatile("" : "+v"(bq[d][n]));
+          if (WEIGHTED) asm volatile("" : "+v"(wq[d]));
+#if !defined(NGD_DIAG_NOLOAD)
+          fetch_x(d ^ 1, kidx(kg + d + 1));  // (past the slice: the images' tail, never consumed)
+#endif
+          __builtin_amdgcn_sched_barrier(0);  // the fetch stays AHEAD of the MFMAs
+#if defined(NGD_DIAG_NOMFMA)
+          if (false) {
+#else
+          if (kg + d < kg1) {
+#endif
+            if (WEIGHTED) {
+              const double w = wq[d];
+#pragma unroll
+              for (int m = 0; m < PM; m++) a[d][m] *= w;
+            }
+#pragma unroll
+            for (int m = 0; m < PM; m++)
+#pragma unroll
+              for (int n = 0; n < PN; n++)
+                if (!TRI || m <= n)
+                  acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     uint64_t nxt[D];
 #pragma unroll
     for (int d = 0; d < D; d++) fetch_x(d, kidx(kg0 + d));
@@ -313,6 +374,87 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // EXACT = 5: the same blocks, operands through LDS (see the note at the kernel).  One barrier per k-group: behind it the
+  // k-group's fragments are complete in stage[b] (written in the previous trip) and nobody reads stage[b ^ 1] any more,
+  // which this trip fills with the NEXT k-group (fetched during the previous trip) before the fetch after next goes out.
+  auto run_lds = [&](auto rows_c, auto cols_c, auto tri_c) {
+    constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value;
+    constexpr bool TRI = decltype(tri_c)::value;
+    if constexpr (EXACT == 5) {
+      // [buffer][row groups 0..15 | column groups 16..31][lane]: dynamic LDS (one array for every block shape's code path)
+      extern __shared__ double ngd_stage_lds[];
+      double(*stage)[32][64] = (double(*)[32][64])ngd_stage_lds;
+      typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+      const uint32_t nw = blockDim.x >> 6, n_igv = n_igv_touch, nf = 2 * n_igv;
+      // This wavefront's share of a k-group's fragments: f = wave, wave + nw, ... -- DEPTH of them in every wavefront (the
+      // launcher's ceil(nf / nw); an index past the last fragment repeats it: same bytes to the same place).  No branch
+      // inside the k loop: the hand-issued loads are invisible to the compiler, and a register copy it placed at a join
+      // would read a register the load has not written yet.
+      constexpr int CNT = DEPTH;
+      // PF k-groups of fetches in flight per wavefront (register sets of CNT doubles): with one, the workgroups hold
+      // ~5 MB in flight device-wide and HBM delivers 3.5 TB/s; its latency under load wants ~12 MB for 5.5
+#if !defined(NGD_LDS_PF)
+#define NGD_LDS_PF 4
+#endif
+      constexpr int PF = NGD_LDS_PF, U = PF < 2 ? 2 : PF;  // the k loop is unrolled U times: buffer and set by position
+      static_assert((PF == 1 || PF == 2 || PF == 4) && PF + U <= NGD_KG_TAIL, "the fetch runs PF + U k-groups past the slice at most");
+      double st[PF][CNT];
+      const double *src[CNT];
+      uint32_t slot[CNT];
+#pragma unroll
+      for (int q = 0; q < CNT; q++) {
+        uint32_t f = wave + q * nw;
+        f = f < nf ? f : nf - 1;
+        src[q] = f < n_igv ? PA + (uint64_t)f * 64 : QB + (uint64_t)(f - n_igv) * 64;
+        slot[q] = f < n_igv ? f : 16 + (f - n_igv);
+      }
+      auto gload = [&](int set, uint64_t kg) {
+#pragma unroll
+        for (int q = 0; q < CNT; q++) load_frag<0>(st[set][q], lane_off, src[q] + kg * kstride);
+      };
+      auto lwrite = [&](uint32_t b, int set) {
+#pragma unroll
+        for (int q = 0; q < CNT; q++) {
+          asm volatile("" : "+v"(st[set][q]));  // read only behind the wait
+          stage[b][slot[q]][lane] = st[set][q];
+        }
+      };
+      gload(0, kg0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lwrite(0, 0);
+#pragma unroll
+      for (int i = 0; i < PF; i++) gload(i, kg0 + 1 + i);  // set i holds k-group kg0 + 1 + i, then every PF-th after it
+      for (uint64_t kg = kg0; kg < kg1; kg += U) {
+#pragma unroll
+        for (int t = 0; t < U; t++) {  // (every trip runs its barrier, LDS traffic and fetch; only the MFMAs end at kg1)
+          constexpr int dummy = 0;
+          (void)dummy;
+          const uint32_t b = t & 1;
+          const int set = t % PF;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the fetches stay in flight)
+          double xa[PM], xb[PN];
+#pragma unroll
+          for (int m = 0; m < PM; m++) xa[m] = *(lds_cvd *)&stage[b][ig0 + m][lane];
+#pragma unroll
+          for (int n = 0; n < PN; n++) xb[n] = *(lds_cvd *)&stage[b][16 + jg0 + n][lane];
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * (PF - 1)) : "memory");  // the oldest set, k-group kg + t + 1, is here
+          lwrite(b ^ 1, set);
+          __builtin_amdgcn_sched_barrier(0);
+          gload(set, kg + t + 1 + PF);  // (past the slice: the images' tail, never consumed)
+          __builtin_amdgcn_sched_barrier(0);
+          if (kg + t < kg1) {
+#pragma unroll
+            for (int m = 0; m < PM; m++)
+#pragma unroll
+              for (int n = 0; n < PN; n++)
+                if (!TRI || m <= n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[m], xb[n], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   using std::integral_constant;
   typedef integral_constant<int, 1> I1;
   typedef integral_constant<int, 2> I2;
@@ -337,6 +479,18 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         default:  // any other shape: the full pattern is always right
           if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{});
       }
+    } else if constexpr (EXACT == 5) {
+      switch (shape) {
+        case 2 | 4 << 3: run_lds(I2{}, I4{}, std::false_type{}); break;
+        case 2 | 3 << 3: run_lds(I2{}, I3{}, std::false_type{}); break;
+        case 2 | 2 << 3: run_lds(I2{}, I2{}, std::false_type{}); break;
+        case 2 | 1 << 3: run_lds(I2{}, I1{}, std::false_type{}); break;
+        case 2 | 4 << 3 | 1 << 6: run_lds(I2{}, I4{}, std::true_type{}); break;
+        case 2 | 3 << 3 | 1 << 6: run_lds(I2{}, I3{}, std::true_type{}); break;
+        case 2 | 2 << 3 | 1 << 6: run_lds(I2{}, I2{}, std::true_type{}); break;
+        case 1 | 1 << 3 | 1 << 6: run_lds(I1{}, I1{}, std::true_type{}); break;
+        default: break;
+      }
     } else {  // EXACT 2 / 4: blocks of at most 2 x 4 tiles (engine.hip builds no other shapes for them), DEPTH k-groups in flight
       typedef integral_constant<int, DEPTH> ID;
       switch (shape) {
@@ -353,6 +507,13 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     }
   }
 
+  if (clk_wave) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      clk[0] = t1 - clk_t0;
+      clk[1] = r1 - clk_r0;
+    }
+  }
   // D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*r
   double *out = slab + (uint64_t)ks * n_pad * n_pad;
 #pragma unroll
@@ -373,20 +534,27 @@ __global__ __launch_bounds__(EXACT == 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
                            int exact_shapes /* 3: n_wg = 1 workgroup of wg_waves wavefronts per slice */, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
-                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab) {
+                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab, unsigned long long *d_clk) {
   if (!n_wg) return;
   // EXACT = 3: a prefetching wavefront beside the jobs where a twelfth fits and the slices are plain k-group ranges
   uint32_t touch_igv = 0;
-  if (((exact_shapes == 3 && wg_waves <= 11) || (exact_shapes == 4 && wg_waves <= 15)) && !d_ws && !d_kgl && !k_per_slice) {
-    touch_igv = (uint32_t)((g.n_ind + 15) / 16);
+  const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);
+  // EXACT = 5 (operands through LDS): plain k-group ranges, at most 16 groups a side and 4 fragments per wavefront;
+  // weighted passes and masked slices of the same engine take the register form (EXACT = 4) of the same jobs
+  if (exact_shapes == 5 && (d_ws || d_kgl || k_per_slice || n_igv > 16 || 2 * n_igv > 4 * wg_waves)) exact_shapes = 4;
+  if (exact_shapes == 5) {
+    touch_igv = n_igv;
+  } else if (((exact_shapes == 3 && wg_waves <= 11) || (exact_shapes == 4 && wg_waves <= 15)) && !d_ws && !d_kgl && !k_per_slice) {
+    touch_igv = n_igv;
     wg_waves += 1;
   }
   // n_ks is a multiple of 8 (see the deal in the kernel)
   // EXACT: one job per (single-wavefront) workgroup -- jobs of different shapes last differently, and a
   // wavefront that is done should not wait for three siblings before its slot is handed on
 #define NGD_MFMA(W, D, P, X)                                                                                    \
-  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X >= 3 ? 64 * wg_waves : X ? 64 : 256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, \
-                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv)
+  hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X >= 3 ? 64 * wg_waves : X ? 64 : 256),       \
+                     X == 5 ? 2 * 32 * 64 * sizeof(double) : 0, st, PA, QB, d_ws, d_kgl, d_jobs,                        \
+                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv, d_clk)
   // No in-wave run-ahead (DEPTH 1), 3 wavefronts per SIMD: the third wavefront covers the others' load phases.
   // Measured against a 4-deep register ring at 2 wavefronts per SIMD (56.0 vs 51.0 ms on the same job layout) and
   // against LDS-staged operand panels (tools/experiments/accum_mfma_lds.hip; profiles/r01_cfg3_mfma_*): both lose.
@@ -398,9 +566,16 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
     constexpr int X2D = NGD_EXACT2_DEPTH;
     constexpr int X2W = X2D == 1 ? 6 : X2D == 2 ? 5 : 4;  // wavefronts per SIMD the registers allow
     if (d_ws) NGD_MFMA(true, X2D, (X2W > 5 ? 5 : X2W), 2); else NGD_MFMA(false, X2D, X2W, 2);  // (weighted: 84 registers at depth 1)
+  } else if (exact_shapes == 5) {  // (DEPTH = fragments a wavefront fetches per k-group)
+    switch ((2 * n_igv + wg_waves - 1) / wg_waves) {
+      case 1: NGD_MFMA(false, 1, 4, 5); break;
+      case 2: NGD_MFMA(false, 2, 4, 5); break;
+      case 3: NGD_MFMA(false, 3, 4, 5); break;
+      default: NGD_MFMA(false, 4, 4, 5); break;
+    }
   } else if (exact_shapes == 4) {
 #if !defined(NGD_EXACT4_DEPTH)
-#define NGD_EXACT4_DEPTH 1
+#define NGD_EXACT4_DEPTH 2  // two register sets: the next k-group's fetch is issued ahead of this one's MFMAs
 #endif
     if (d_ws) NGD_MFMA(true, NGD_EXACT4_DEPTH, 4, 4); else NGD_MFMA(false, NGD_EXACT4_DEPTH, 4, 4);
   } else if (exact_shapes == 3) {

@@ -56,8 +56,11 @@ struct ngd_engine {
   ngd_tile *d_tiles = nullptr, *d_tiles16 = nullptr, *d_tiles64 = nullptr;
   uint32_t n_tiles = 0, n_tiles16 = 0, n_tiles64 = 0;
   int em_shape = 0;  // accum_em_table.hip: workgroup shape
-  unsigned long long *d_emcnt = nullptr;  // [2] work counters of the table-driven EM kernel
+  unsigned long long *d_emcnt = nullptr;  // [4] work counters of the table-driven EM kernel + its clock counters
   unsigned long long em_counts[2] = {0, 0};  // ... of the last run
+  unsigned long long *d_clk = nullptr;  // [2] MFMA kernel: shader-cycle / constant-rate counter deltas of one wavefront
+  double clk_mhz = 0;                   // shader clock of the last accumulation launch (0: not sampled)
+  double wall_khz = 100000.0;           // rate of the constant counter (hipDeviceAttributeWallClockRate)
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
   ngd_job *d_jobs = nullptr;
   uint32_t n_wg = 0;
@@ -106,6 +109,7 @@ struct ngd_engine {
   // plan options (ngd_set_option)
   uint64_t opt_boot_partials = 1, opt_boot_max_bytes = 0, opt_boot_wg = 4096, opt_boot_unaligned = 1, opt_em_batch = 1;
   uint64_t opt_em_spill = 1, opt_em_spill_bytes = 0;
+  bool em_batch_nofit = false;  // the EM batch pass's result planes did not fit this device: not tried again
   // EM bootstrap by spilled terms + one MFMA contraction (contract_mfma.hip): running sums and per-chunk NaN flags
   double *d_D = nullptr;
   unsigned long long *d_nanflag = nullptr;
@@ -171,7 +175,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag, e->d_clk};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -197,9 +201,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
-  if (cfg->exact_shapes > 5)
+  if (cfg->exact_shapes > 6)
     return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
-                               "(4 x 4, a slice's jobs in one workgroup) or 5 (2 x 4, one workgroup)");
+                               "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup) or 6 (5 with operands "
+                               "through LDS)");
   if (cfg->variant > 4) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
   const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
   if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
@@ -245,6 +250,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   e->device = dev;
   e->kernel = kernel;
   memcpy(e->sc.v, cfg->score, sizeof(e->sc.v));
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) e->wall_khz = khz;
+  }
 
   ngd_geom &g = e->g;
   g.n_ind = cfg->n_ind;
@@ -300,11 +309,12 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   const uint32_t n_igv = (uint32_t)((g.n_ind + 15) / 16);  // groups that hold at least one individual
   // auto: up to 384 individuals only the tiles a block needs are issued (accum_mfma.hip EXACT); where a slice's jobs fit
   // one workgroup they run in step, each operand fragment leaving HBM once: up to 13 groups of 16 individuals as 16
-  // blocks of 2 x 4 tiles, up to 16 groups as 10 blocks of 4 x 4 ([measured] 100 000 sites, ms per matrix, plain / in step:
-  // n_ind = 200: 0.356 / 0.302; 250: 0.427 / 0.387; 100: 0.143 / 0.146; engine.hip falls back where they do not fit)
+  // blocks of 2 x 4 tiles with the operands staged through LDS, up to 16 groups as 10 blocks of 4 x 4 ([measured]
+  // 100 000 sites, ms per matrix, plain / in step: n_ind = 100: 0.143 / 0.108; 200: 0.356 / 0.262; 250: 0.427 / 0.387;
+  // the forms fall back where a slice's jobs do not fit one workgroup)
   e->exact_shapes = cfg->exact_shapes ? (cfg->exact_shapes == 1 ? 0 : (int)cfg->exact_shapes - 1)
-                                      : (g.n_pad > 384 ? 0 : n_igv <= 13 ? 4 : n_igv <= 16 ? 3 : 1);
-  if (e->exact_shapes == 2 || e->exact_shapes == 4) {
+                                      : (g.n_pad > 384 ? 0 : n_igv <= 13 ? 5 : n_igv <= 16 ? 3 : 1);
+  if (e->exact_shapes == 2 || e->exact_shapes >= 4) {
     // strips of two row groups, cut into blocks of four column groups from the diagonal on (the first block of a strip
     // is triangular: 7 tiles of 8); an odd last row is its diagonal tile.  Under pair-tile sharding blocks must not
     // straddle a 128-tile (8 groups): the first block of a strip then ends at the next multiple of four.
@@ -365,7 +375,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     // the jobs are dealt, most expensive first, to the least loaded of four bins and wavefront w takes bin w % 4's
     // next job.  At most 12 wavefronts of 4 x 4 blocks (3 per SIMD at that kernel's register count) or 16 of 2 x 4:
     // else the plain exact form of the same blocks.
-    const bool small = e->exact_shapes == 4;
+    const bool small = e->exact_shapes >= 4;
     auto cost = [&](const ngd_job &j) {
       return small ? (j.tri ? j.rows * j.cols - (j.rows > 1 ? 1 : 0) : j.rows * j.cols)
                    : (j.tri ? j.rows * (j.rows + 1) / 2 : j.rows * j.cols);
@@ -477,7 +487,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
                                        ? (uint32_t)prop.multiProcessorCount / 8 : 32;
       // (in-step forms: whole workgroups of wg_waves jobs + the prefetching wavefront, 20 / 12 wavefronts to a CU)
       const uint32_t sync_wgs = e->exact_shapes >= 3
-                                    ? std::max(1u, (e->exact_shapes == 4 ? 20u : 12u) / std::min(16u, e->wg_waves + 1)) : 0;
+                                    ? std::max(1u, (e->exact_shapes >= 4 ? 20u : 12u) / std::min(16u, e->wg_waves + 1)) : 0;
       const double slots = (double)cus_per_xcd * (e->exact_shapes >= 3 ? sync_wgs : e->exact_shapes == 2 ? 24 : e->exact_shapes ? 12 : 3);
       // ... plus what the slice count costs afterwards: the slab reduction reads one plane per slice ([measured] 0.8 us
       // per slice at n_ind = 1000, i.e. ~5 TB/s), against an accumulation pass at ~0.8 of the FP64 peak.  It decides
@@ -499,6 +509,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+    TRY(dev_alloc(e, &e->d_clk, 2, true));
   } else if (kernel == NGD_KERNEL_EM_TABLE) {
     // 64 x 64 tiles x slices of sites; a workgroup works a site in ~10 us, so slices of a few thousand sites keep
     // the tail of the launch short without making the slab large
@@ -511,7 +522,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
-    TRY(dev_alloc(e, &e->d_emcnt, 2, true));
+    TRY(dev_alloc(e, &e->d_emcnt, 4, true));
   } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
     uint64_t want = cfg->wg_target ? cfg->wg_target : 4096;
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
@@ -677,7 +688,7 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
     case NGD_KERNEL_MFMA:
       ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
                               (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
-                              kg_lim, k_per_slice, w_stride, slab);
+                              kg_lim, k_per_slice, w_stride, slab, e->d_clk);
       break;
     case NGD_KERNEL_EM_TABLE:
       ngd_launch_accum_em_table(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del, e->em_shape, e->d_tiles64,
@@ -691,12 +702,18 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
 
 static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool add) {
   if (e->d_emcnt) {  // the stream is idle: counters of the pass(es) since the last read
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     if (hipMemcpy(c, e->d_emcnt, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
       if (!add) e->em_counts[0] = e->em_counts[1] = 0;
       e->em_counts[0] += c[0]; e->em_counts[1] += c[1];
+      if (c[3]) e->clk_mhz = (double)c[2] / (double)c[3] * e->wall_khz * 1e-3;
       hipMemsetAsync(e->d_emcnt, 0, sizeof(c), e->st);
     }
+  }
+  if (e->d_clk && launches) {
+    unsigned long long c[2] = {0, 0};
+    if (hipMemcpy(c, e->d_clk, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[1])
+      e->clk_mhz = (double)c[0] / (double)c[1] * e->wall_khz * 1e-3;
   }
   float ms[4] = {0, 0, 0, 0};
   hipEventElapsedTime(&ms[0], e->ev[0], e->ev[4]);
@@ -767,12 +784,16 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
     launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[2], e->st));
-  if (e->kernel != NGD_KERNEL_STREAM) ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, d_sum);
+  // (without --pairwise_del the reduction writes the counts too: every pair visits the same number of sites)
+  const bool cnt_in_reduce = e->kernel != NGD_KERNEL_STREAM && !e->cfg.pairwise_del;
+  if (e->kernel != NGD_KERNEL_STREAM)
+    ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, d_sum, cnt_in_reduce ? d_cnt : nullptr,
+                      mult ? n_drawn : n_eff);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
     ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles, e->n_tiles, d_cnt);
-  } else {
+  } else if (!cnt_in_reduce) {
     ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, mult ? n_drawn : n_eff, nullptr, 1, d_cnt);
   }
   HIPCHK(hipGetLastError());
@@ -1216,7 +1237,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   const bool em_pair = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
   const bool em_table_batch = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0 && n_rep + lead >= 3;
   const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape != 0 && n_rep >= 3;
-  if ((em_pair || em_borrow || em_table_batch) && n_rep + lead >= 2 && e->opt_em_batch) {
+  if ((em_pair || em_borrow || em_table_batch) && n_rep + lead >= 2 && e->opt_em_batch && !e->em_batch_nofit) {
     const bool fold = lead && e->kernel != NGD_KERNEL_EM_FAITHFUL;
     if (lead && !fold) {
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
@@ -1228,6 +1249,8 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
     // matrices are computed one pass each instead (the allocation is tried before anything is launched)
     if (rc != NGD_E_NOMEM) return rc;
     (void)hipGetLastError();
+    g_err.clear();  // not an error of this call: the matrices are computed one pass each instead
+    if (!e->opt_boot_max_bytes) e->em_batch_nofit = true;  // the device's verdict (not a caller's budget): remembered
     if (lead && !fold) {  // matrix 0 is done already
       for (uint32_t r = 0; r < n_rep; r++) {
         rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[lead + r], n_blocks, block_size, drawn[lead + r],
@@ -1386,6 +1409,12 @@ int ngd_last_em_work(const ngd_engine *e, uint64_t *tile_sites, uint64_t *table_
   if (!e) return fail(NGD_E_INVALID, "ngd_last_em_work: null engine");
   if (tile_sites) *tile_sites = e->em_counts[0];
   if (table_rounds) *table_rounds = e->em_counts[1];
+  return NGD_OK;
+}
+
+int ngd_last_shader_clock(const ngd_engine *e, double *mhz) {
+  if (!e || !mhz) return fail(NGD_E_INVALID, "ngd_last_shader_clock: null argument");
+  *mhz = e->clk_mhz;
   return NGD_OK;
 }
 

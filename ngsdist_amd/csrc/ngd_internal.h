@@ -107,7 +107,8 @@ void ngd_launch_accum_stream(hipStream_t st, const ngd_geom &g, const double *PI
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_wk, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
                            int exact_shapes, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
-                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab);
+                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab,
+                           unsigned long long *d_clk /* [2] or NULL: shader-cycle / constant-rate counter deltas of one wavefront */);
 
 // accum_em.hip : per-site EM, one thread per pair of a 16x16 tile
 void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
@@ -119,7 +120,7 @@ void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, co
 void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int shape,
                                const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice,
-                               double *slab, unsigned long long *d_counters /* [2]: += (tile, site) visits, table rounds */);
+                               double *slab, unsigned long long *d_counters /* [4]: += (tile, site) visits, table rounds; [2..3] = clock counters */);
 
 // accum_em_table.hip, rb (4 or 8) matrices in one pass: d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
 void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
@@ -156,8 +157,10 @@ void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *
 // reduce.hip : deterministic slab reduction + valid-site counting
 // planes_per_slice: the slab holds that many result planes per slice (EM batch kernel), `slab` points at
 // the first slice's plane of the wanted result
+// d_cnt != NULL: every pair's count is set to cnt_value in the same launch (no --pairwise_del)
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum);
+                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
+                       unsigned long long *d_cnt = nullptr, unsigned long long cnt_value = 0);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,

@@ -18,9 +18,12 @@ __device__ __forceinline__ bool ngd_finite(double v) { return __builtin_fabs(v) 
 // grid = owned 128-tiles x 128 rows; 128 threads = columns.  Eight interleaved partial sums (slice
 // ks goes to partial ks % 8) keep eight loads in flight per thread; they are combined in a fixed tree,
 // so the result is a fixed function of the slabs (deterministic), just not the left-to-right sum.
+// d_cnt != NULL: the pair's count is written too (no --pairwise_del: the same number of sites for every pair,
+// ngsDist.cpp:362) -- one launch less per matrix, which a 0.3 ms job notices.
 __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab, uint32_t n_ks,
                                                  uint32_t planes_per_slice, const ngd_tile *__restrict__ tiles,
-                                                 uint32_t n_pad, uint64_t n_ind, double *__restrict__ d_sum) {
+                                                 uint32_t n_pad, uint64_t n_ind, double *__restrict__ d_sum,
+                                                 unsigned long long *__restrict__ d_cnt, unsigned long long cnt_value) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
@@ -34,7 +37,9 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
     for (int u = 0; u < 8; u++) s[u] += p[(uint64_t)(ks + u) * plane];
   }
   for (int u = 0; ks < n_ks; ks++, u++) s[u] += p[(uint64_t)ks * plane];
-  d_sum[ngd_pair_idx(n_ind, i, j)] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+  d_sum[idx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (d_cnt) d_cnt[idx] = cnt_value;
 }
 
 // Bootstrap replicates from per-block partial sums, RB replicates per pass over the slab:
@@ -282,10 +287,11 @@ void reduce_cb(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_
 }  // namespace
 
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
-                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
+                       uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
+                       unsigned long long *d_cnt, unsigned long long cnt_value) {
   if (!n_tiles) return;
   hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, planes_per_slice, d_tiles,
-                     g.n_pad, g.n_ind, d_sum);
+                     g.n_pad, g.n_ind, d_sum, d_cnt, cnt_value);
 }
 
 // replicates per pass over the partials; the weight arrays are padded to a multiple of it

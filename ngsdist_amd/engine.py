@@ -222,6 +222,12 @@ class Engine:
         _check(self._L.ngd_last_em_work(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def shader_clock_mhz(self):
+        """shader clock of the last MFMA / table-driven EM launch, sampled inside the kernel (0.0: not sampled)"""
+        v = C.c_double(0.0)
+        _check(self._L.ngd_last_shader_clock(self._h, C.byref(v)))
+        return float(v.value)
+
     def device_bytes(self):
         return int(self._L.ngd_device_bytes(self._h))
 

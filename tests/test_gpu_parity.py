@@ -424,7 +424,7 @@ def test_shards_partition_the_pairs(kernel):
 
 
 @pytest.mark.parametrize("n_ind", [17, 33, 130, 200, 383, 600])
-@pytest.mark.parametrize("form", [2, 3, 4, 5])
+@pytest.mark.parametrize("form", [2, 3, 4, 5, 6])
 def test_mfma_exact_block_forms(n_ind, form):
     """exact_shapes 2 / 3 / 4 (accum_mfma.hip EXACT): only the MFMA tiles a block needs, in blocks of up to 4 x 4, 2 x 4, or 4 x 4 with a slice's jobs in one workgroup (up to 12 jobs; else form 2):
     tiles of 16 x 16 pairs -- every pair against the oracle; called genotypes bit for bit; a bootstrap replicate as a
@@ -612,6 +612,31 @@ def test_all_zero_site_under_em_poisons_only_the_replicates_that_draw_it(kernel,
         assert rel_err(S[r][ok], so[ok]) < RTOL
         if m is not None:
             assert np.array_equal(np.isnan(S1[r - 1]), np.isnan(so))
+
+
+@pytest.mark.parametrize("spill", [0, 1])
+def test_raw_likelihoods_whose_sum_is_denormal_stay_in_the_matrices_that_draw_them(spill):
+    """a RAW upload (the reference's prepared input sums to 1) whose three likelihoods sum below 2^-1022: the table
+    kernel's reciprocal of that sum is inf and the pair's term not finite -- in the matrices that draw the site, as from
+    a one-matrix pass; the matrices that do NOT draw it must stay finite and equal to their own pass (no 0 x NaN), in
+    the 8-matrix pass and in the spilled-terms plan alike."""
+    n_ind, n_sites, B = 9, 64, 8
+    p = O.synth_indmajor(12, n_ind, n_sites)
+    p[4, 17] = (3e-310, 1e-310, 2e-310)  # block 2
+    t = N().Taus(21)
+    maps = np.stack([t.block_map(n_sites // B) for _ in range(10)])
+    assert any(2 in m for m in maps) and any(2 not in m for m in maps)
+    with N().Engine(n_ind, n_sites, indep_geno=False, kernel="em_table") as e:
+        e.set_option("boot_partials", 0).set_option("em_spill", spill)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, B)
+        for r, m in enumerate(maps):
+            s1, c1 = e.run(m, B)
+            assert np.array_equal(Cn[r + 1], c1)
+            assert np.array_equal(np.isfinite(S[r + 1]), np.isfinite(s1)), (r, m)
+            ok = np.isfinite(s1)
+            assert (2 in m) == (not ok.all())
+            assert rel_err(S[r + 1][ok], s1[ok]) < 1e-12
 
 
 @pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)

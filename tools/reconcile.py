@@ -14,10 +14,9 @@ a, b = last_line(sys.argv[1]), last_line(sys.argv[2])
 ra, rb = a["roofline"], b["roofline"]
 off = abs(b["ms_per_step"] / a["ms_per_step"] - 1.0)
 for name, d, r in (("unprofiled", a, ra), ("kernel-trace pass", b, rb)):
-    clk = r.get("sclk_mhz") or {}
-    print("%-18s ms_per_step %.4f, kernel ms per launch mean %.4f min %.4f median %.4f, frac %s, sclk median %s MHz"
+    print("%-18s ms_per_step %.4f, kernel ms per launch mean %.4f min %.4f median %.4f, frac %s, shader clock in the kernel %s MHz"
           % (name, d["ms_per_step"], r["ms_per_launch"], r.get("ms_per_launch_min", float("nan")),
              r.get("ms_per_launch_median", float("nan")), "%.4f" % r["frac"] if r.get("frac") is not None else "n/a",
-             clk.get("median")))
+             "%.0f" % r["shader_clock_mhz"] if r.get("shader_clock_mhz") else "n/a"))
 print("ms_per_step of the traced run is %.2f %% off the unprofiled one: %s" % (100 * off, "ok (<= 2 %)" if off <= 0.02 else "NOT within 2 %"))
 sys.exit(0 if off <= 0.02 else 1)
