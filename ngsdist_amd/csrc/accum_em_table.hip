@@ -394,6 +394,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     clk_t0 = __builtin_amdgcn_s_memtime();
     clk_r0 = __builtin_amdgcn_s_memrealtime();
   }
+#if defined(NGD_EMT_YOUNG_FIRST)
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);  // A/B build: the younger half of the workgroup is served first
+#endif
   const uint64_t s0 = site_base + (uint64_t)ks * sites_per_slice;
   uint64_t s1 = s0 + sites_per_slice;
   if (s1 > n_sites_eff) s1 = n_sites_eff;
@@ -416,8 +419,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
   constexpr int NP = NW / 2;     // wavefronts per role
   constexpr int SEG = CH / NP;   // steps per wavefront and round
   static_assert(CH % NP == 0, "shape");
+  // The column builders do more per step (they apply the score), and of two wavefronts of a workgroup that share a SIMD
+  // the older one is served first: NGD_EMT_SWAP_ROLES (A/B build) gives the columns to the older wavefronts.
+#if defined(NGD_EMT_SWAP_ROLES)
+  const bool is_row = wave >= NP;
+  const uint32_t seg = is_row ? wave - NP : wave;
+#else
   const bool is_row = wave < NP;
   const uint32_t seg = is_row ? wave : wave - NP;
+#endif
   const uint32_t bind = (is_row ? I0 : J0) + lane;
   const double *pb = PA + (uint64_t)(bind >> 4) * 64 + (bind & 15);
   const uint64_t kstride = (uint64_t)n_ig * 64;  // doubles between consecutive k-groups
@@ -546,11 +556,20 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
             const uint32_t pref = need_a >> 1;           // rows that fetch their successor's
             ngd_d2 QA[4];
 #pragma unroll
-            for (int r = 0; r < RPW; r++)
+            for (int r = 0; r < RPW; r++) {
+#if defined(NGD_EMT_FAIR)
+              // A/B build: of the two wavefronts of a workgroup that share a SIMD the older is served first and reaches
+              // every barrier ~9 % earlier (cycle stamps); alternating their priorities row by row shares the SIMD evenly
+              if (((r & 1) != 0) != (wave >= NW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
               if ((go >> r) & 1)
                 scan_row<CH, WEIGHTED, PACK, RB>(L, (wave * RPW + r) * RS, (wave * RPW + r + 1) * RS, lane, r, R2, QA,
                                                  todo, acc[r], wv, ((ska >> r) & 1) | (((skb >> r) & 1) << 1),
                                                  (load >> r) & 1, (pref >> r) & 1);
+            }
+#if defined(NGD_EMT_FAIR)
+            __builtin_amdgcn_s_setprio(0);
+#endif
           }
           if (t0 != 0) packed_units<CH, WEIGHTED, RB>(L, wave, lane, todo, acc, wv);
         }

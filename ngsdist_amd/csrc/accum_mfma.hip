@@ -114,12 +114,16 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
   if (TOUCH && toucher) {  // (wave-uniform)
     const uint64_t ks_d = (uint64_t)n_ig * 64;
     const uint32_t lo = lane * 8;
-    double sink;
+    // The loads land in `sink` whenever they land: the register must stay this wavefront's own from the first load to
+    // the final wait.  Every load therefore READS and writes it ("+v": one unbroken def-use chain) -- as a plain output
+    // the compiler counted it dead between two loads and put the loop bound there, which a late-returning fragment then
+    // overwrote (found by tools/fuzz_parity.py case 40501: 64 individuals, no zero padding in the last group).
+    double sink = 0.0;
     auto touch = [&](uint64_t kg) {
       const double *xa = PA + kg * ks_d, *xb = QB + kg * ks_d;
       for (uint32_t gi = 0; gi < n_igv_touch; gi++) {
-        load_frag<0>(sink, lo, xa + gi * 64);
-        load_frag<0>(sink, lo, xb + gi * 64);
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(sink) : "v"(lo), "s"(xa + gi * 64));
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(sink) : "v"(lo), "s"(xb + gi * 64));
       }
     };
     // (plain k-group ranges only: the engine gives this form no k-group list and no per-slice weights; a slice past the

@@ -239,6 +239,36 @@ def test_cfg4_full_size_block_additivity(cfg4_em):
     assert rel(s_lo + s_hi, 2 * full) < 1e-12
 
 
+def test_em_bootstrap_job_of_a_hundred_replicates_by_spilled_terms():
+    """cfg 4's shape on 1e5 sites with the reference's own kind of bootstrap (parse_args.cpp:29-31: EM, blocks far too
+    small for per-block partials): the full data + 100 replicates of 10-site blocks through ngd_run_job -- ONE EM pass,
+    its terms spilled in chunks and contracted with the 101 weight vectors by FP64 MFMA (contract_mfma.hip).  Several
+    chunks (2 GB of scratch), counts exact, matrix 0 and four replicates <= 1e-12 from their own passes, the identity
+    block map reproduces the full data, and 6 pairs of the last replicate against the oracle over all its sites."""
+    n_ind, n_sites, B, n_rep = 1000, 100_000, 10, 100
+    rng = N().Taus(11)
+    maps = np.stack([rng.block_map(n_sites // B) for _ in range(n_rep)])
+    maps[1] = np.arange(n_sites // B, dtype=np.uint64)  # every block once: the full data
+    with N().Engine(n_ind, n_sites, indep_geno=False, kernel="em_table") as e:
+        e.synth_fill(3).set_option("boot_partials", 0).set_option("em_spill_bytes", 2 << 30)
+        S, Cn = e.run_job(maps, B)
+        assert e.timing()["launches"] == 1
+        s0, c0 = e.run()
+        assert np.array_equal(Cn[0], c0) and rel(S[0], s0) < 1e-12 and rel(S[2], s0) < 1e-12
+        for r in (0, 49, 98, 99):
+            s1, c1 = e.run(maps[r], B)
+            assert np.array_equal(Cn[r + 1], c1) and rel(S[r + 1], s1) < 1e-12
+    idx = [0, 1, n_ind // 2, n_ind - 1]
+    sub = np.concatenate([O.synth_indmajor(3, n_ind, n_sites, i0=i, n_sub=1) for i in idx])
+    so, co = O.all_pairs(sub, indep_geno=False, site_src=O.boot_site_src(maps[-1], B), n_sites=n_sites, n_threads=6)
+    k = 0
+    for a in range(4):
+        for b in range(a + 1, 4):
+            g = S[-1][N().n_pairs(n_ind) - N().n_pairs(n_ind - idx[a]) + (idx[b] - idx[a] - 1)]
+            assert abs(g - so[k]) / abs(so[k]) < RTOL
+            k += 1
+
+
 @pytest.mark.parametrize("kernel,indep", [("mfma", True), ("stream", True), ("em_table", False), ("em_fast", False)])
 def test_tens_of_thousands_of_individuals(kernel, indep):
     """n_ind = 16 000 (1.28e8 pairs, a 2 GB slab plane; 20 000 and 40 000 were run by hand at the end of round 2): index

@@ -423,13 +423,15 @@ def test_shards_partition_the_pairs(kernel):
     assert np.array_equal(tot_c, co) and rel_err(tot_s, so) < RTOL
 
 
-@pytest.mark.parametrize("n_ind", [17, 33, 130, 200, 383, 600])
+@pytest.mark.parametrize("n_ind", [17, 33, 64, 130, 200, 256, 383, 600])
 @pytest.mark.parametrize("form", [2, 3, 4, 5, 6])
 def test_mfma_exact_block_forms(n_ind, form):
     """exact_shapes 2 / 3 / 4 (accum_mfma.hip EXACT): only the MFMA tiles a block needs, in blocks of up to 4 x 4, 2 x 4, or 4 x 4 with a slice's jobs in one workgroup (up to 12 jobs; else form 2):
     tiles of 16 x 16 pairs -- every pair against the oracle; called genotypes bit for bit; a bootstrap replicate as a
     weighted pass, from per-block partials with blocks of 8 sites and with blocks of 6 (masked slices); pair-tile
-    shards that partition the pairs (blocks must not straddle a 128-tile)."""
+    shards that partition the pairs (blocks must not straddle a 128-tile).  64 and 256 individuals: the last group of 16
+    holds no zero padding (the in-step forms' prefetching wavefront once lost its loop bound to a late-returning
+    fragment there: tools/fuzz_parity.py case 40501)."""
     n_sites = 1030
     p = O.synth_indmajor(41 + n_ind, n_ind, n_sites, miss_frac=0.1)
     so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)

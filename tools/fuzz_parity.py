@@ -30,7 +30,9 @@ for case in range(first, first + n_cases):
     B = min(int(rng.choice([1, 2, 3, 4, 7, 8, 12, 50, 100])), n_sites)
     n_rep = int(rng.choice([0, 1, 2, 3, 5, 17, 33]))
     partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
-    geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 3)) if kernel == "mfma" else 0,
+    em_spill = int(rng.integers(0, 3))  # 0 off, 1 from three matrices on, 2 from two on (table-driven EM kernel)
+    spill_bytes = int(rng.choice([0, 0, 1 << 20, 3 << 20])) if em_spill else 0  # a few k-groups of terms per chunk
+    geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 7)) if kernel == "mfma" else 0,
                 variant=int(rng.integers(0, 5)) if kernel == "em_table" else 0)
     score = O.score_matrix(bool(rng.integers(0, 2)))
     model = int(rng.integers(0, 3))
@@ -41,7 +43,7 @@ for case in range(first, first + n_cases):
     n_eff = n_sites - n_sites % B
     t = N.Taus(case)
     maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
-    tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, geom)
+    tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, em_spill, spill_bytes, geom)
     big = False
     mode = int(rng.integers(0, 3))  # 0: one engine; 1: site ranges (partial multiplicities); 2: pair-tile shards
     tag = tag + (("one", "site ranges", "pair tiles")[mode],)
@@ -74,6 +76,7 @@ for case in range(first, first + n_cases):
                     kw = dict(shard_rank=r, shard_world=world)
                 with N.Engine(n_ind, hi - lo, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom, **kw) as e:
                     e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
+                    e.set_option("em_spill", em_spill).set_option("em_spill_bytes", spill_bytes)
                     e.upload_ind_major(sub).commit()
                     s0, c0 = e.run()
                     S[0] += s0
@@ -85,6 +88,7 @@ for case in range(first, first + n_cases):
         else:
           with N.Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
             e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
+            e.set_option("em_spill", em_spill).set_option("em_spill_bytes", spill_bytes)
             e.upload_ind_major(p).commit()
             S, Cn = e.run_job(maps, B)
         for m in sorted({0, n_rep // 2, n_rep}):
