@@ -235,6 +235,17 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
 #pragma unroll
   for (int h = 0; h < 4; h++) QB[h] = *(ngd_lds_cvd2 *)&L.Qr[rb + 8 + 2 * h];
   uint32_t n = 8;  // steps survived (by the lanes in m; the others keep what they had when they stopped)
+#if defined(NGD_EMT_DIAG_COARSE)
+  // TIMING-ONLY build (results wrong): what the search would cost if only every other step were compared (the upper
+  // bound of a coarse search + one refining compare: DESIGN.md section 8)
+  n = 0;
+  if ((skip & 3) != 3)
+    scan8(m, n, R2[1], R2[3], R2[5], R2[7], R2[9], R2[11], R2[13], R2[15], QA[0][1], QA[1][1], QA[2][1], QA[3][1], QB[0][1],
+          QB[1][1], QB[2][1], QB[3][1]);
+  else n = 8;
+  const uint32_t lim = 8;
+  const int T = mine && n < lim ? 2 * (int)n + 2 : 0;
+#else
   if (!(skip & 1)) {
     n = 0;
     scan8(m, n, R2[0], R2[1], R2[2], R2[3], R2[4], R2[5], R2[6], R2[7], QA[0][0], QA[0][1], QA[1][0], QA[1][1], QA[2][0],
@@ -246,6 +257,7 @@ __device__ __forceinline__ void scan_row(const em_tables<CH, PACK> &L, uint32_t 
     scan8(m, n, R2[8], R2[9], R2[10], R2[11], R2[12], R2[13], R2[14], R2[15], QB[0][0], QB[0][1], QB[1][0], QB[1][1],
           QB[2][0], QB[2][1], QB[3][0], QB[3][1]);
   const int T = mine && n < lim ? (int)n + 1 : 0;
+#endif
   const uint32_t ti = T ? T - 1 : 0;
   const uint32_t a = rb + ti, b = ti * TS + lane;
   const double f0 = lds_b64(&L.Fr[0][a]), g0 = lds_b64(&L.Gc[0][b]);
