@@ -220,6 +220,11 @@ int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint6
                 uint64_t block_size, double *sum, uint64_t *cnt);
 int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks,
                        uint64_t block_size, void *d_sum, void *d_cnt);
+/* ngd_run_batch / ngd_run_mult_batch / ngd_run_job with sum = cnt = NULL leave their matrices in the engine; this copies
+ * matrix `which` of that last call (0 = the first it computed) to the caller -- a host that prints the matrices one after
+ * the other (ngsDist.cpp:282-287) then needs two n_pairs-long buffers, not (n_boot_rep + 1) of them.  Valid until the
+ * engine's next run call. */
+int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt);
 
 /* Bootstrap replicates re-use per-block partial (sum, cnt) computed on the first
  * run that carries a block map (valid for that block size / block count;

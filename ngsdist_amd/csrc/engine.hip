@@ -95,6 +95,7 @@ struct ngd_engine {
   double *d_bsum = nullptr;
   unsigned long long *d_bcnt = nullptr;
   uint64_t cap_batch = 0;
+  uint32_t n_batch_valid = 0;  // matrices of the last batch / job call, still in d_bsum / d_bcnt (ngd_fetch_matrix)
   double *staging = nullptr;
   uint64_t staging_sites = 0;
   // raw-input pipeline: two pinned host buffers + two device buffers, alternating
@@ -1275,6 +1276,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
 
 static int copy_out(ngd_engine *e, uint32_t n_mat, const double *d_sum, const unsigned long long *d_cnt, double *sum,
                     uint64_t *cnt) {
+  e->n_batch_valid = d_sum == e->d_bsum ? n_mat : 0;
   const uint64_t n = (uint64_t)n_mat * ngd_n_pairs(e->g.n_ind);
   if (sum) HIPCHK(hipMemcpy(sum, d_sum, n * sizeof(double), hipMemcpyDeviceToHost));
   if (cnt) HIPCHK(hipMemcpy(cnt, d_cnt, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1370,6 +1372,16 @@ int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint6
   rc = run_impl(e, block_maps, nullptr, n_rep, n_rep != 0, n_blocks, block_size, e->d_bsum, e->d_bcnt);
   if (rc) return rc;
   return copy_out(e, n_rep + 1, e->d_bsum, e->d_bcnt, sum, cnt);
+}
+
+int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_fetch_matrix: null engine");
+  if (which >= e->n_batch_valid) return fail(NGD_E_INVALID, "ngd_fetch_matrix: no such matrix in the engine's last batch");
+  HIPCHK(hipSetDevice(e->device));
+  const uint64_t n = ngd_n_pairs(e->g.n_ind);
+  if (sum) HIPCHK(hipMemcpy(sum, e->d_bsum + (uint64_t)which * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (cnt) HIPCHK(hipMemcpy(cnt, e->d_bcnt + (uint64_t)which * n, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return NGD_OK;
 }
 
 int ngd_set_option(ngd_engine *e, int option, uint64_t value) {

@@ -1041,7 +1041,17 @@ int main(int argc, char **argv) {
     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
   };
 
-  const uint64_t kBatch = 32;
+  // Matrices per engine call.  --indep_geno: 32 (the engine forms 32 replicates per pass over the per-block partials).
+  // EM path: the per-site EM does not depend on the replicate and ONE pass of it serves every matrix of a call (the
+  // engine spills the per-(pair, site) terms and contracts them with all the weight vectors: contract_mfma.hip), so the
+  // whole job goes in one call where its results (16 B per cell) and block maps fit a few GB of host memory.
+  uint64_t kBatch = 32;
+  if (!p.indep_geno && p.n_boot_rep + 1 > kBatch) {
+    const uint64_t by_results = (4ull << 30) / std::max<uint64_t>(1, n_comb * 16);
+    const uint64_t blocks = p.boot_block_size ? p.n_sites / p.boot_block_size : 0;
+    const uint64_t by_maps = blocks ? (2ull << 30) / (blocks * 8) : ~0ull;
+    kBatch = std::max<uint64_t>(kBatch, std::min({by_results, by_maps, (uint64_t)p.n_boot_rep + 1}));
+  }
   fflush(stdout);
   if (in_parts) {
     // ---- the site axis in ranges: side by side on the devices, one after the other where they are too small ----
@@ -1195,22 +1205,35 @@ int main(int argc, char **argv) {
   std::vector<uint64_t> cnt, block_maps;
   uint64_t n_sites = p.n_sites;
 
+  // A batch's matrices stay in the engine and come to the host one at a time, as they are printed (ngd_fetch_matrix):
+  // the host holds two n_pairs-long buffers, not a batch of them ([measured] 1000 individuals, 101 matrices: the 0.8 GB
+  // of zero-filled result vectors and their page faults cost 1.5 s, three times the engine's whole job).
+  bool in_engine = false;  // this batch's matrices are fetched from the engine
   auto run_all = [&](const uint64_t *maps, uint32_t n_rep, bool with_full, uint64_t n_blocks) {
-    const uint64_t n_mat = n_rep + (with_full ? 1 : 0);
-    sum.assign(n_mat * n_comb, 0.0);
-    cnt.assign(n_mat * n_comb, 0);
+    in_engine = false;
     if (n_rep && n_blocks == 0) {
       // fewer sites than one bootstrap block: the reference truncates the replicates to 0 sites (ngsDist.cpp:236),
       // visits none and prints 0/0; the full data set is still a plain run
+      const uint64_t n_mat = n_rep + (with_full ? 1 : 0);
+      sum.assign(n_mat * n_comb, 0.0);
+      cnt.assign(n_mat * n_comb, 0);
       if (with_full) {
         int rc = ngd_run(eng.h, nullptr, 0, 0, sum.data(), cnt.data());
         if (rc) die_engine("ngd_run", rc);
       }
       return;
     }
-    int rc = with_full ? ngd_run_job(eng.h, maps, n_rep, n_blocks, p.boot_block_size, sum.data(), cnt.data())
-                       : ngd_run_batch(eng.h, maps, n_rep, n_blocks, p.boot_block_size, sum.data(), cnt.data());
+    sum.resize(n_comb);
+    cnt.resize(n_comb);
+    if (!n_rep) {  // the full data alone
+      int rc = ngd_run(eng.h, nullptr, 0, 0, sum.data(), cnt.data());
+      if (rc) die_engine("ngd_run", rc);
+      return;
+    }
+    int rc = with_full ? ngd_run_job(eng.h, maps, n_rep, n_blocks, p.boot_block_size, nullptr, nullptr)
+                       : ngd_run_batch(eng.h, maps, n_rep, n_blocks, p.boot_block_size, nullptr, nullptr);
     if (rc) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rc);
+    in_engine = true;
   };
 
   for (uint64_t rep = 0; rep <= p.n_boot_rep;) {
@@ -1227,9 +1250,16 @@ int main(int argc, char **argv) {
     }
     run_all(block_maps.data(), (uint32_t)n_boot_here, with_full, n_blocks);
     t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
-    for (uint64_t r = 0; r < n_in_batch; r++, rep++)
-      emit(rep, &sum[r * n_comb], &cnt[r * n_comb],
+    for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
+      if (in_engine) {
+        const auto t_g0 = std::chrono::steady_clock::now();
+        int rc = ngd_fetch_matrix(eng.h, (uint32_t)r, sum.data(), cnt.data());
+        if (rc) die_engine("ngd_fetch_matrix", rc);
+        t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_g0).count();
+      }
+      emit(rep, in_engine ? sum.data() : &sum[r * n_comb], in_engine ? cnt.data() : &cnt[r * n_comb],
            rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks);
+    }
   }
   }
   fclose(out_fh);

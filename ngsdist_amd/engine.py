@@ -196,6 +196,20 @@ class Engine:
                                    c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
+    def run_job_keep(self, block_maps, block_size=1):
+        """ngd_run_job with the matrices left in the engine; fetch_matrix(r) copies them out one at a time"""
+        a = np.ascontiguousarray(block_maps, dtype=np.uint64)
+        n_rep, n_blocks = a.shape
+        _check(self._L.ngd_run_job(self._h, a.ctypes.data_as(C.POINTER(C.c_uint64)), n_rep, n_blocks, int(block_size), None, None))
+        return n_rep + 1
+
+    def fetch_matrix(self, which):
+        s = np.empty(self.n_pairs, dtype=np.float64)
+        c = np.empty(self.n_pairs, dtype=np.uint64)
+        _check(self._L.ngd_fetch_matrix(self._h, int(which), s.ctypes.data_as(C.POINTER(C.c_double)),
+                                        c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return s, c
+
     def run_device(self, d_sum_ptr, d_cnt_ptr, block_map=None, block_size=1):
         """Results written to caller-owned device buffers (raw addresses)."""
         ptr, nb, bs, keep = self._map_args(block_map, block_size)

@@ -19,6 +19,7 @@ struct ngd_engine {
   bool committed = false;
   uint64_t seen_sites = 0;
   double checksum = 0;
+  uint32_t kept = 0;  // matrices of the last batch call left "in the engine" (ngd_fetch_matrix)
 };
 
 static std::string g_err;
@@ -82,10 +83,21 @@ int ngd_commit(ngd_engine *e) {
   return NGD_OK;
 }
 static int fill(ngd_engine *e, uint32_t n_mat, uint64_t n_blocks, uint64_t B, bool need_blocks, double *sum, uint64_t *cnt) {
-  if (!e || !e->committed || !sum || !cnt) return fail(NGD_E_INVALID, "stub: run");
+  if (!e || !e->committed || (!sum != !cnt)) return fail(NGD_E_INVALID, "stub: run");
   if (need_blocks && (!B || !n_blocks || n_blocks > e->cfg.n_sites / B)) return fail(NGD_E_INVALID, "stub: block geometry");
   const uint64_t np = ngd_n_pairs(e->cfg.n_ind);
+  e->kept = 0;
+  if (!sum) {  // the matrices stay "in the engine" for ngd_fetch_matrix
+    e->kept = n_mat;
+    return NGD_OK;
+  }
   for (uint64_t k = 0; k < n_mat * np; k++) { sum[k] = 0.25 * (double)(k % 7); cnt[k] = 1 + k % 3; }
+  return NGD_OK;
+}
+int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt) {
+  if (!e || which >= e->kept || !sum || !cnt) return fail(NGD_E_INVALID, "stub: fetch_matrix");
+  const uint64_t np = ngd_n_pairs(e->cfg.n_ind);
+  for (uint64_t k = 0; k < np; k++) { sum[k] = 0.25 * (double)((which * np + k) % 7); cnt[k] = 1 + (which * np + k) % 3; }
   return NGD_OK;
 }
 int ngd_run(ngd_engine *e, const uint64_t *bm, uint64_t nb, uint64_t B, double *sum, uint64_t *cnt) {

@@ -85,6 +85,9 @@ def test_stdin_binary_and_log_scale(tmp_path):
     # more replicates than one engine batch (32), blocks that leave a tail of sites, per-block partial (sum, cnt)
     (["--indep_geno", "--pairwise_del", "--n_boot_rep", "40", "--boot_block_size", "12", "--seed", "7", "--n_threads", "3"],
      dict(n_boot_rep=40, boot_block_size=12, seed=7, pairwise_del=True)),
+    # EM path: the whole job (full data + 40 replicates) goes to the engine in ONE call -- the per-site EM serves them all
+    (["--n_boot_rep", "40", "--boot_block_size", "3", "--seed", "11", "--evol_model", "2"],
+     dict(n_boot_rep=40, boot_block_size=3, seed=11, indep_geno=False, evol_model=2)),
 ])
 def test_flag_combinations_against_oracle_flow(tmp_path, flags, kw):
     raw = np.fromfile(T_GL, dtype=np.float64)

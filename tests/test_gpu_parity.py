@@ -367,6 +367,28 @@ def test_em_bootstrap_by_spilled_terms_and_one_contraction(n_ind, n_sites, block
         assert np.array_equal(Cn[m], co) and rel_err(S[m], so) < RTOL
 
 
+@pytest.mark.parametrize("kernel", ["mfma", "em_table"])
+def test_matrices_of_a_job_fetched_one_at_a_time(kernel):
+    """ngd_run_job with NULL outputs leaves the matrices in the engine; ngd_fetch_matrix copies them out one by one (what
+    the C++ host does: it prints a matrix at a time and holds two n_pairs-long buffers, not n_boot_rep + 1 of them) --
+    the same bits as the all-at-once call; an index past the batch, or a fetch after another run, is an error code."""
+    n_ind, n_sites, B = 33, 400, 4
+    p = O.synth_indmajor(3, n_ind, n_sites, miss_frac=0.1)
+    maps = np.stack([N().Taus(r).block_map(n_sites // B) for r in range(5)])
+    with N().Engine(n_ind, n_sites, pairwise_del=True, indep_geno=kernel == "mfma", kernel=kernel) as e:
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, B)
+        assert e.run_job_keep(maps, B) == 6
+        for r in range(6):
+            s, c = e.fetch_matrix(r)
+            assert np.array_equal(s, S[r]) and np.array_equal(c, Cn[r])
+        with pytest.raises(N().engine.NgdError):
+            e.fetch_matrix(6)
+        e.run()
+        with pytest.raises(N().engine.NgdError):
+            e.fetch_matrix(0)
+
+
 @pytest.mark.parametrize("kernel", ["em_table", "em_fast", "em_faithful"])
 def test_em_batch_pass_that_does_not_fit_falls_back_to_one_pass_per_matrix(kernel):
     """the EM batch pass needs RB result planes per slice; when they exceed the scratch budget (NGD_OPT_BOOT_MAX_BYTES,
