@@ -548,7 +548,8 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
   if (exact_shapes == 5 && (d_ws || d_kgl || k_per_slice || n_igv > 16 || 2 * n_igv > 4 * wg_waves)) exact_shapes = 4;
   if (exact_shapes == 5) {
     touch_igv = n_igv;
-  } else if (((exact_shapes == 3 && wg_waves <= 11) || (exact_shapes == 4 && wg_waves <= 15)) && !d_ws && !d_kgl && !k_per_slice) {
+  } else if (((exact_shapes == 3 && wg_waves <= 11) || (exact_shapes == 4 && wg_waves <= 15)) && !d_ws && !d_kgl && !k_per_slice &&
+             n_igv <= 16) {  // (the prefetching wavefront keeps 24 + 2 n_igv loads in flight: the counter holds 63)
     touch_igv = n_igv;
     wg_waves += 1;
   }
