@@ -431,8 +431,6 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
       for (uint64_t kg = kg0; kg < kg1; kg += U) {
 #pragma unroll
         for (int t = 0; t < U; t++) {  // (every trip runs its barrier, LDS traffic and fetch; only the MFMAs end at kg1)
-          constexpr int dummy = 0;
-          (void)dummy;
           const uint32_t b = t & 1;
           const int set = t % PF;
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the fetches stay in flight)
