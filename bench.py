@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
+    ap.add_argument("--single_image", action="store_true",
+                    help="ngd_config.single_image: hold one operand image, form the other per launch (memory for time)")
+    ap.add_argument("--single_image_gb", type=float, default=0.0,
+                    help="with --single_image: GB of the second image formed at a time (NGD_OPT_SINGLE_IMAGE_BYTES; 0 = 4)")
     ap.add_argument("--exact_shapes", type=int, default=0,
                     help="ngd_config.exact_shapes: the MFMA kernel's block form (0 = the engine's choice; experiments)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
@@ -188,14 +192,16 @@ def main():
         lo = (n_units * rank // world) * unit
         hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
         eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       exact_shapes=args.exact_shapes)
+                       exact_shapes=args.exact_shapes, single_image=args.single_image)
         eng.synth_fill(W["seed"], args.miss_frac, site0=lo)
         blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
     else:
         lo, hi = 0, n_sites
         eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes)
+                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes, single_image=args.single_image)
         eng.synth_fill(W["seed"], args.miss_frac)
+    if args.single_image and args.single_image_gb > 0:
+        eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
@@ -756,6 +762,7 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
+                   "device_bytes": eng.device_bytes(), "single_image": bool(args.single_image),
                    "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
                                "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
                                "device buffers, copied to pinned host memory"),

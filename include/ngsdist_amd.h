@@ -76,7 +76,12 @@ typedef struct ngd_config {
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 / 3 = always issue only the MFMA tiles a     */
                          /* block needs, in blocks of up to 4 x 4 / 2 x 4 tiles of 16 x 16 pairs       */
                          /* (auto: when n_ind padded to 128 is at most 384)                            */
-  uint32_t reserved[2];  /* must be zero                                                               */
+  uint32_t single_image; /* NGD_KERNEL_MFMA: 1 = hold ONE operand image (p) and form the score-weighted one  */
+                         /* (q = score . p, ngsDist.cpp:351-353 regrouped) for a range of sites at a time,  */
+                         /* before the launch that reads it: 31 GB instead of 51 for 1000 x 1e6 -- twice the  */
+                         /* sites per engine -- for a quarter more time; sums equal to rounding, per-block   */
+                         /* partial sums bit for bit                                   */
+  uint32_t reserved[1];  /* must be zero                                                               */
 } ngd_config;
 
 /* Per-run device timings (HIP events on the engine's stream). */
@@ -249,6 +254,9 @@ int ngd_drop_caches(ngd_engine *e);
                                  /*     0 never, 1 from 3 matrices on, 2 from 2 on.  Matrices then agree with their own */
                                  /*     ngd_run() pass to rounding (<= 1e-12 relative), not bit for bit                 */
 #define NGD_OPT_EM_SPILL_BYTES 7 /* [0 = 6 GB] device scratch for those terms (bounds the sites per chunk)             */
+#define NGD_OPT_SINGLE_IMAGE_BYTES 8 /* [0 = 4 GB] ngd_config.single_image engines: bytes of the second operand image */
+                                 /*     formed at a time (a pass is so many launches; never less than 64 k-groups per */
+                                 /*     slice, or eight bootstrap blocks of a partial-sum pass); set before the first run */
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);

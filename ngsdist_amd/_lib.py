@@ -28,7 +28,8 @@ class NgdConfig(C.Structure):
         ("n_slices", C.c_uint32),
         ("wg_target", C.c_uint32),
         ("exact_shapes", C.c_uint32),
-        ("reserved", C.c_uint32 * 2),
+        ("single_image", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
 
 

@@ -71,12 +71,13 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
     uint32_t n_pad, uint64_t kg_per_slice, uint64_t n_kg, uint64_t k_per_slice, uint32_t w_slice_stride,
-    double *__restrict__ slab, uint32_t n_igv_touch = 0, unsigned long long *__restrict__ clk = nullptr) {
+    double *__restrict__ slab, uint32_t n_igv_touch = 0, unsigned long long *__restrict__ clk = nullptr,
+    uint32_t ks0 = 0, uint32_t resume = 0) {
   // XCD-aware deal: blocks b and b+8 share an XCD (round-robin dispatch; speed only).
   const uint32_t b = blockIdx.x;
   const uint32_t xcd = b & 7u, q = b >> 3;
   const uint32_t tile = q % n_tiles;
-  const uint32_t ks = (q / n_tiles) * 8u + xcd;
+  const uint32_t ks = ks0 + (q / n_tiles) * 8u + xcd;  // (ks0: a launch over a range of the pass's slices)
   // the wavefront index is uniform: say so, so that operand addresses live in SGPRs
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // EXACT = 3 with n_igv_touch != 0: the workgroup's last wavefront computes nothing -- it reads every operand fragment
@@ -527,7 +528,11 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         if (EXACT && (m >= (int)(shape & 7) || n >= (int)((shape >> 3) & 7) || ((shape >> 6) && m > n))) continue;  // (uniform)
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
-        out[(uint64_t)i * n_pad + j] = acc[m][n][r];
+        // (resume: single-image engines walk a pass in ranges of k-groups, every slice a piece of each range -- the
+        // block's sums over this range are added to what the launches over the earlier ranges left in its plane)
+        double v = acc[m][n][r];
+        if (resume) v = out[(uint64_t)i * n_pad + j] + v;
+        out[(uint64_t)i * n_pad + j] = v;
       }
 }
 
@@ -536,7 +541,8 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
 void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, const double *QB,
                            const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
                            int exact_shapes /* 3: n_wg = 1 workgroup of wg_waves wavefronts per slice */, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
-                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab, unsigned long long *d_clk) {
+                           uint64_t k_per_slice, uint32_t w_slice_stride, double *slab, unsigned long long *d_clk,
+                           uint32_t ks0, uint32_t resume) {
   if (!n_wg) return;
   // EXACT = 3: a prefetching wavefront beside the jobs where a twelfth fits and the slices are plain k-group ranges
   uint32_t touch_igv = 0;
@@ -557,7 +563,7 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
 #define NGD_MFMA(W, D, P, X)                                                                                    \
   hipLaunchKernelGGL((k_accum_mfma<W, D, P, X>), dim3(n_wg * n_ks), dim3(X >= 3 ? 64 * wg_waves : X ? 64 : 256),       \
                      X == 5 ? 2 * 32 * 64 * sizeof(double) : 0, st, PA, QB, d_ws, d_kgl, d_jobs,                        \
-                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv, d_clk)
+                     n_wg, g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv, d_clk, ks0, resume)
   // No in-wave run-ahead (DEPTH 1), 3 wavefronts per SIMD: the third wavefront covers the others' load phases.
   // Measured against a 4-deep register ring at 2 wavefronts per SIMD (56.0 vs 51.0 ms on the same job layout) and
   // against LDS-staged operand panels (tools/experiments/accum_mfma_lds.hip; profiles/r01_cfg3_mfma_*): both lose.

@@ -44,6 +44,11 @@ struct ngd_engine {
   hipEvent_t ev[5] = {};
   // resident data set
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
+  // ngd_config.single_image (MFMA kernel): QB is not resident; a launch forms it for a range of k-groups at a time
+  bool single_image = false;
+  double *qb_chunk = nullptr;
+  uint64_t qb_chunk_kg = 0;     // k-groups a range may span (NGD_OPT_SINGLE_IMAGE_BYTES)
+  uint64_t qb_chunk_elems = 0;  // capacity of the scratch
   unsigned long long *mask = nullptr, *planes = nullptr;
   // bootstrap
   uint32_t *d_mult = nullptr, *d_ws = nullptr;
@@ -139,6 +144,20 @@ static int ensure_cap(ngd_engine *e, T **p, uint64_t *cap, uint64_t need) {
   return NGD_OK;
 }
 
+// Single-image engines: k-groups of the second operand image formed at a time by default (4 GB of them)
+static uint64_t single_image_span(const ngd_geom &g) {
+  return std::max<uint64_t>(1, std::min<uint64_t>(g.n_kg, (4ull << 30) / ((uint64_t)g.n_ig * 64 * 8)));
+}
+
+// Single-image engines, a whole pass in ranges: the piece of a range one slice takes (k-groups: whole pipeline trips, and
+// long enough to carry a block's 128 KB of running sums in and out) so that a range is about `span` k-groups.
+static uint64_t qb_piece(uint64_t kg_lim, uint32_t n_ks, uint64_t span, uint64_t *n_ranges) {
+  uint64_t r = std::max<uint64_t>(1, (kg_lim + span - 1) / span);
+  const uint64_t piece = std::max<uint64_t>(64, ((kg_lim + r * n_ks - 1) / (r * n_ks) + 3) / 4 * 4);
+  *n_ranges = std::max<uint64_t>(1, (kg_lim + piece * n_ks - 1) / (piece * n_ks));
+  return piece;
+}
+
 extern "C" {
 
 const char *ngd_last_error(void) { return g_err.c_str(); }
@@ -174,7 +193,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
+  void *ptrs[] = {e->PA, e->QB, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag, e->d_clk};
   for (void *p : ptrs)
@@ -202,6 +221,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
   for (uint32_t r : cfg->reserved)
     if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
+  if (cfg->single_image > 1) return fail(NGD_E_INVALID, "ngd_create: single_image is 0 or 1");
   if (cfg->exact_shapes > 6)
     return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
                                "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup) or 6 (5 with operands "
@@ -457,7 +477,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     TRY(dev_alloc(e, &e->PI, g.n_ind * g.n_sites_pad * 3, true));
   } else {
     TRY(dev_alloc(e, &e->PA, frag_elems, true));
-    if (kernel == NGD_KERNEL_MFMA) TRY(dev_alloc(e, &e->QB, frag_elems, true));
+    e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image;
+    if (kernel == NGD_KERNEL_MFMA && !e->single_image) TRY(dev_alloc(e, &e->QB, frag_elems, true));
   }
   if (cfg->pairwise_del) {
     TRY(dev_alloc(e, &e->mask, g.n_ind * (uint64_t)g.n_words, true));
@@ -496,11 +517,16 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       // of 248 (6.36 instead of 6.54 ms per matrix, the accumulation itself is flat from 88 to 500 slices).
       const double accum_s = 6.0 * (double)e->n_owned_pairs * (double)g.n_sites / (0.8 * 78.6e12);
       const double reduce_s_per_slice = 8.0 * (double)e->n_owned_pairs / 5e12;
+      // A single-image engine walks the pass in ranges (launch_accumulate()): every launch has all the slices, and every
+      // block adds to its plane of the slab at the end of each ([measured] cfg 3, 248 slices, 12 ranges: +0.53 ms per
+      // launch, 2.1 us per slice -- 2.7 reductions' worth).  Fewer slices then: as few as fill their rounds.
+      const uint64_t qb_ranges = e->single_image ? std::max<uint64_t>(1, (g.n_kg + single_image_span(g) - 1) / single_image_span(g)) : 0;
+      const double per_slice_s = reduce_s_per_slice * (1.0 + 2.7 * (double)qb_ranges);
       double best = 1e30;
       uint64_t best_ks = ks;
-      for (uint64_t c = std::max<uint64_t>(8, ks / 3 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
+      for (uint64_t c = e->single_image ? 8 : std::max<uint64_t>(8, ks / 3 / 8 * 8); c <= std::min(max_ks, ks * 115 / 100); c += 8) {
         const double rounds = (double)wg_per_slice * (double)(c / 8) / slots;
-        const double waste = std::ceil(rounds - 1e-9) / rounds + (double)c * reduce_s_per_slice / std::max(accum_s, 1e-9);
+        const double waste = std::ceil(rounds - 1e-9) / rounds + (double)c * per_slice_s / std::max(accum_s, 1e-9);
         if (waste < best) { best = waste; best_ks = c; }
       }
       ks = best_ks;
@@ -511,6 +537,15 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
     TRY(dev_alloc(e, &e->d_clk, 2, true));
+    if (e->single_image) {
+      // scratch for QB: one range of a whole pass (launch_accumulate(); partial-sum passes grow it if a bootstrap
+      // block is longer)
+      e->qb_chunk_kg = single_image_span(g);
+      uint64_t n_ranges = 0;
+      const uint64_t range_kg = std::min<uint64_t>(g.n_kg, qb_piece(g.n_kg, e->n_ks, e->qb_chunk_kg, &n_ranges) * e->n_ks);
+      e->qb_chunk_elems = (range_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64;
+      TRY(dev_alloc(e, &e->qb_chunk, e->qb_chunk_elems, false));
+    }
   } else if (kernel == NGD_KERNEL_EM_TABLE) {
     // 64 x 64 tiles x slices of sites; a workgroup works a site in ~10 us, so slices of a few thousand sites keep
     // the tail of the launch short without making the slab large
@@ -681,15 +716,71 @@ int ngd_synth_fill(ngd_engine *e, uint64_t seed, double miss_frac) { return ngd_
 // per_slice / kg_lim count list entries
 // k_per_slice != 0 (MFMA, bootstrap blocks that are not whole k-groups): slices of k_per_slice contraction indices,
 // masked by the per-slice 0/1 weights in e->d_wslice (w_stride k-groups per slice)
-static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *kgl, uint64_t sites_eff, uint32_t n_ks,
+static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *kgl, uint64_t sites_eff, uint32_t n_ks,
                               uint64_t per_slice, uint64_t kg_lim, double *slab, uint64_t k_per_slice = 0,
                               uint32_t w_stride = 0) {
   const ngd_geom &g = e->g;
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
-      ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
-                              (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
-                              kg_lim, k_per_slice, w_stride, slab, e->d_clk);
+      if (!e->single_image) {
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
+                                (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
+                                kg_lim, k_per_slice, w_stride, slab, e->d_clk);
+      } else {
+        // QB is formed range by range into a scratch (k_qb_range: HBM work, 49 GB a pass at cfg 3) on the accumulation
+        // kernel's own stream, each range before the launch that reads it.
+        //  * a whole pass (slab == e->slab): EVERY slice takes a piece of every range, so that each launch has the
+        //    pass's full grid (a launch over a few whole slices would not fill the chip once: cfg 3 has 34 workgroups
+        //    per slice and room for 768); a block adds its sums over the range to its plane of the slab (`resume`).  A
+        //    slice is then not one contiguous run of k-groups, as it is with both images resident: the sums of the two
+        //    engines agree to rounding (exactly where the arithmetic is exact: called genotypes), not bit for bit.
+        //  * per-block partial sums (a slice = a bootstrap block, thousands of them): ranges of whole slices, in eights
+        //    (the XCD deal of accum_mfma.hip); the kernel is handed the scratch moved back by the range's first k-group.
+        // (single-image engines make no k-group lists: pass_impl() walks every k-group of a weighted pass)
+        // [measured, cfg 3] forming a range on a second stream beside the launch over the range before it gains nothing:
+        // the accumulation kernel slows by what the overlap hides, however few blocks form the range and with or
+        // without non-temporal accesses (profiles/r04_single_image.txt; tools/experiments/single_image_two_streams.patch).
+        const uint64_t kstride = (uint64_t)g.n_ig * 64;
+        const uint64_t span = std::max<uint64_t>(1, e->qb_chunk_kg);
+        const bool whole_pass = slab == e->slab && !k_per_slice;
+        auto slice_kg0 = [&](uint64_t ks) { return k_per_slice ? (ks * k_per_slice) >> 2 : ks * per_slice; };
+        auto slice_kg1 = [&](uint64_t ks) {
+          return std::min<uint64_t>(kg_lim, k_per_slice ? ((ks + 1) * k_per_slice + 3) >> 2 : (ks + 1) * per_slice);
+        };
+        uint64_t piece = 0, n_ranges = 0;
+        if (whole_pass) piece = qb_piece(kg_lim, n_ks, span, &n_ranges);
+        uint32_t r = 0;
+        for (uint32_t ks0 = 0; whole_pass ? r < n_ranges : ks0 < n_ks; r++) {
+          uint32_t n = 8;
+          uint64_t lo, hi;
+          if (whole_pass) {
+            lo = std::min<uint64_t>((uint64_t)r * piece * n_ks, kg_lim);
+            hi = std::min<uint64_t>(lo + piece * n_ks, kg_lim);
+          } else {
+            while (ks0 + n < n_ks && slice_kg1(ks0 + n + 7) - slice_kg0(ks0) <= span && slice_kg0(ks0 + n) < kg_lim) n += 8;
+            n = std::min(n, n_ks - ks0);
+            lo = std::min<uint64_t>(slice_kg0(ks0), kg_lim);
+            hi = std::max(lo, slice_kg1(ks0 + n - 1));
+          }
+          const uint64_t need = (hi - lo + NGD_KG_TAIL) * kstride;
+          if (need > e->qb_chunk_elems) {
+            // a range longer than the scratch was sized for (bootstrap blocks of very many sites: a partial-sum slice
+            // is a whole block): the scratch grows to hold it -- the earlier ranges' launches have to be over first
+            HIPCHK(hipStreamSynchronize(e->st));
+            int rc = ensure_cap(e, &e->qb_chunk, &e->qb_chunk_elems, need);
+            if (rc) return rc;
+          }
+          ngd_launch_qb_range(e->st, g, e->sc, e->PA, lo, std::min<uint64_t>(hi + NGD_KG_TAIL, g.n_kg + NGD_KG_TAIL), e->qb_chunk);
+          const double *wsel = k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr);
+          if (whole_pass)
+            ngd_launch_accum_mfma(e->st, g, e->PA + lo * kstride, e->qb_chunk, wsel ? wsel + lo * 4 : nullptr, nullptr, e->d_jobs,
+                                  e->n_wg, e->exact_shapes, e->wg_waves, n_ks, piece, hi - lo, 0, 0, slab, e->d_clk, 0, r > 0);
+          else
+            ngd_launch_accum_mfma(e->st, g, e->PA, e->qb_chunk - lo * kstride, wsel, nullptr, e->d_jobs, e->n_wg,
+                                  e->exact_shapes, e->wg_waves, n, per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, ks0);
+          ks0 += n;
+        }
+      }
       break;
     case NGD_KERNEL_EM_TABLE:
       ngd_launch_accum_em_table(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del, e->em_shape, e->d_tiles64,
@@ -699,6 +790,7 @@ static void launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *
       ngd_launch_accum_em(e->st, g, e->PA, w, sites_eff, e->sc, e->cfg.pairwise_del,
                           e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
   }
+  return NGD_OK;
 }
 
 static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool add) {
@@ -738,7 +830,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   const uint32_t *ws = nullptr;
   uint32_t n_planes = 0;
   uint32_t n_list = 0;
-  const bool list_pass = mult && e->kernel == NGD_KERNEL_MFMA;
+  const bool list_pass = mult && e->kernel == NGD_KERNEL_MFMA && !e->single_image;
   HIPCHK(hipEventRecord(e->ev[0], e->st));
   if (mult) {
     n_eff = n_blocks * block_size;
@@ -775,14 +867,16 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   if (zero_sum) HIPCHK(hipMemsetAsync(d_sum, 0, n_pairs * sizeof(double), e->st));
   if (zero_cnt) HIPCHK(hipMemsetAsync(d_cnt, 0, n_pairs * sizeof(unsigned long long), e->st));
   HIPCHK(hipEventRecord(e->ev[1], e->st));
+  int rc_acc = NGD_OK;
   if (e->kernel == NGD_KERNEL_STREAM)
     ngd_launch_accum_stream(e->st, g, e->PI, ws, n_eff, e->sc, e->cfg.pairwise_del,
                             e->cfg.shard_world > 1 ? e->d_pairs : nullptr, e->n_owned_pairs, d_sum);
   else if (list_pass)  // slices are equal shares of the list (whole multiples of 4 entries: the deepest operand ring)
-    launch_accumulate(e, ws, e->d_kgl, n_eff, e->n_ks, (((uint64_t)n_list + e->n_ks - 1) / e->n_ks + 3) / 4 * 4, n_list,
-                      e->slab);
+    rc_acc = launch_accumulate(e, ws, e->d_kgl, n_eff, e->n_ks, (((uint64_t)n_list + e->n_ks - 1) / e->n_ks + 3) / 4 * 4,
+                               n_list, e->slab);
   else
-    launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
+    rc_acc = launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
+  if (rc_acc) return rc_acc;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[2], e->st));
   // (without --pairwise_del the reduction writes the counts too: every pair visits the same number of sites)
@@ -892,10 +986,11 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
       rc = ensure_cap(e, &e->d_wslice, &e->cap_wslice, (uint64_t)e->boot_nks * w_stride * 4);
       if (rc) return rc;
       ngd_launch_slice_weights(e->st, e->boot_nks, w_stride, 3 * block_size, 3 * n_eff, e->d_wslice);
-      launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, 0, (3 * n_eff + 3) / 4, e->slab_boot, 3 * block_size,
-                        w_stride);
+      rc = launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, 0, (3 * n_eff + 3) / 4, e->slab_boot, 3 * block_size,
+                             w_stride);
     } else
-    launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
+      rc = launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, e->boot_per_slice, mfma ? 3 * n_eff / 4 : 0, e->slab_boot);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     e->boot_B = block_size;
     e->boot_blocks = n_blocks;
@@ -1403,6 +1498,10 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       e->opt_em_spill = value;
       break;
     case NGD_OPT_EM_SPILL_BYTES: e->opt_em_spill_bytes = value; break;
+    case NGD_OPT_SINGLE_IMAGE_BYTES:
+      if (!e->single_image) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_SINGLE_IMAGE_BYTES needs ngd_config.single_image");
+      e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
+      break;
     default: return fail(NGD_E_INVALID, "ngd_set_option: unknown option");
   }
   return NGD_OK;

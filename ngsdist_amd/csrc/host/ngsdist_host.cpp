@@ -23,7 +23,8 @@
 //    range of sites and computes all pairs over it; the per-range sums are added -- byte-identical output for called
 //    genotypes, <= 1e-12 relative otherwise), --device D (first device), --same_device (every range on --device: a
 //    rehearsal on one GPU), --max_device_bytes B (device budget; a data set above it goes through in several ranges
-//    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful,
+//    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful, --single_image (--indep_geno on the MFMA
+//    kernel: ngd_config.single_image -- half the device memory per site, so twice the sites per range, a quarter slower),
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -76,6 +77,7 @@ struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
   int n_gpus = 1, device = 0, kernel = NGD_KERNEL_AUTO;
   bool same_device = false;      // --same_device
   uint64_t max_device_bytes = 0; // --max_device_bytes (0 = 85 % of the device's free memory)
+  bool single_image = false;     // --single_image
   int prep = 0;  // 0 auto (device unless genotypes are called), 1 host, 2 device
 };
 
@@ -123,6 +125,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
                                  {"n_gpus", required_argument, nullptr, 1001},
                                  {"same_device", no_argument, nullptr, 1005},
                                  {"max_device_bytes", required_argument, nullptr, 1006},
+                                 {"single_image", no_argument, nullptr, 1007},
                                  {"device", required_argument, nullptr, 1002},
                                  {"kernel", required_argument, nullptr, 1003},
                                  {"prep", required_argument, nullptr, 1004},
@@ -157,6 +160,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
       case 1001: p.n_gpus = atoi(optarg); break;
       case 1005: p.same_device = true; break;
       case 1006: p.max_device_bytes = strtoull(optarg, nullptr, 10); break;
+      case 1007: p.single_image = true; break;
       case 1002: p.device = atoi(optarg); break;
       case 1003:
         if (!strcmp(optarg, "auto")) p.kernel = NGD_KERNEL_AUTO;
@@ -965,6 +969,7 @@ int main(int argc, char **argv) {
     cfg.indep_geno = p.indep_geno;
     cfg.device = p.same_device ? p.device : p.device + dev_index;
     cfg.kernel = p.kernel;
+    cfg.single_image = p.single_image ? 1 : 0;  // (means something to the MFMA kernel only)
     int rc = ngd_create(&cfg, &eng.h);
     if (rc) die_engine("ngd_create", rc);
   };
@@ -977,10 +982,12 @@ int main(int argc, char **argv) {
   // the per-range (sum, cnt) are added.
   const uint64_t n_pad = (p.n_ind + 127) / 128 * 128;
   const bool mfma_path = p.indep_geno && p.kernel != NGD_KERNEL_STREAM;
-  const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path ? 48 : 24) * n_pad) +
+  const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path && !p.single_image ? 48 : 24) * n_pad) +
                             (p.pairwise_del ? p.n_ind / 8 + 1 : 0) + 40;
   const uint64_t n_t = n_pad / 128, n_slabs = std::max<uint64_t>(8, std::min<uint64_t>(256, 8192 / (n_t * (n_t + 1) / 2)));
-  const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);
+  const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20) +
+                         (mfma_path && p.single_image ? std::min<uint64_t>(4ull << 30, 24 * n_pad * p.n_sites) + (64ull << 20)
+                                                      : 0);  // (the range of the second image formed at a time)
   uint64_t dev_free = 0, dev_total = 0;
   if (ngd_device_memory(p.device, &dev_free, &dev_total)) die_engine("ngd_device_memory", -1);
   if (p.same_device) dev_free /= (uint64_t)p.n_gpus;  // the rehearsal's ranges share one device

@@ -34,6 +34,53 @@ __device__ __forceinline__ void emit(const ngd_geom &g, const ngd_score &sc, int
   }
 }
 
+// Three k-groups hold 12 contraction indices = 4 WHOLE sites: a wavefront takes one group of 16 individuals through
+// QB_PER such periods -- whole 512-byte fragments in, whole fragments out, a site's three values exchanged through LDS
+// (lane (k % 4, i % 16) of fragment f holds index 4 f + k % 4 of the period).  k-groups outside [kg_lo, kg_hi) belong
+// to other ranges and are not written; those past the image's tail read as zero.
+constexpr int QB_PER = 4;
+__global__ __launch_bounds__(256) void k_qb_range(ngd_geom g, ngd_score sc, const double *__restrict__ PA, uint64_t u_lo,
+                                                  uint64_t u_hi, uint64_t kg_lo, uint64_t kg_hi, double *__restrict__ QBs) {
+  __shared__ double t[4][QB_PER][192];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, ii = lane & 15;
+  const uint32_t n_q = g.n_ig >> 2;  // (n_pad is a multiple of 128: n_ig of 8)
+  const uint64_t kg_end = g.n_kg + NGD_KG_TAIL;
+  // this lane's row of the score matrix in each of a period's three fragments: index 4 f + kk is genotype (f + kk) % 3
+  double c[3][3];
+#pragma unroll
+  for (int f = 0; f < 3; f++) {
+    const uint32_t a = (f + kk) % 3;
+#pragma unroll
+    for (int b = 0; b < 3; b++) c[f][b] = a == 0 ? sc.v[b] : a == 1 ? sc.v[3 + b] : sc.v[6 + b];
+  }
+  const uint32_t ig = (blockIdx.x % n_q) * 4 + wave;
+  const uint64_t u0 = u_lo + (uint64_t)(blockIdx.x / n_q) * QB_PER;
+  double p[QB_PER][3];
+#pragma unroll
+  for (int u = 0; u < QB_PER; u++)
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+      const uint64_t kg = 3 * (u0 + u) + f;
+      p[u][f] = (u0 + u < u_hi && kg < kg_end) ? PA[(kg * g.n_ig + ig) * 64 + lane] : 0.0;
+    }
+#pragma unroll
+  for (int u = 0; u < QB_PER; u++)
+#pragma unroll
+    for (int f = 0; f < 3; f++) t[wave][u][f * 64 + lane] = p[u][f];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < QB_PER; u++)
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+      const uint64_t kg = 3 * (u0 + u) + f;
+      const uint32_t s3 = (4 * f + kk) / 3 * 3;  // first index of this lane's site within the period
+      double q = c[f][0] * t[wave][u][s3 * 16 + ii];
+      q = q + c[f][1] * t[wave][u][(s3 + 1) * 16 + ii];
+      q = q + c[f][2] * t[wave][u][(s3 + 2) * 16 + ii];
+      if (u0 + u < u_hi && kg >= kg_lo && kg < kg_hi) QBs[((kg - kg_lo) * g.n_ig + ig) * 64 + lane] = q;
+    }
+}
+
 __global__ void k_layout(ngd_geom g, const double *__restrict__ raw, int raw_ind_major, uint64_t s0,
                          uint64_t n_chunk, ngd_score sc, int pairwise_del, double *PA, double *QB,
                          double *PI, unsigned long long *mask) {
@@ -285,6 +332,18 @@ void ngd_launch_kg_compact(hipStream_t st, const double *d_wk, uint64_t n_kg, ui
   hipLaunchKernelGGL(k_kg_scan, dim3(1), dim3(1024), 0, st, d_counts, nb);
   hipLaunchKernelGGL(k_kg_scatter, dim3(nb), dim3(256), 0, st, d_wk, n_kg, d_counts, d_list);
   hipLaunchKernelGGL(k_kg_pad, dim3(1), dim3(64), 0, st, d_list, d_counts + nb, (uint32_t)NGD_KG_LIST_PAD, tail_kg);
+}
+
+// Single-image engines (ngd_config.single_image): the score-weighted image QB is not resident; before a launch of the MFMA
+// kernel over k-groups [kg_lo, kg_hi) it is formed from PA into a scratch (element (i, k) at ngd_frag_off(k, i) minus the
+// range's first k-group) with layout.hip's own arithmetic (emit() above: q[g1] = sum_g2 score[g1][g2] * p[g2], products
+// and sums rounded one by one), so the kernel's results carry the same bits as with both images resident.
+void ngd_launch_qb_range(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *PA, uint64_t kg_lo,
+                         uint64_t kg_hi, double *QBs) {
+  if (kg_hi <= kg_lo) return;
+  const uint64_t u_lo = kg_lo / 3, u_hi = (kg_hi + 2) / 3;  // every period of three k-groups with one in the range
+  const uint64_t n_blk = (u_hi - u_lo + QB_PER - 1) / QB_PER * (g.n_ig >> 2);
+  hipLaunchKernelGGL(k_qb_range, dim3((unsigned)n_blk), dim3(256), 0, st, g, score, PA, u_lo, u_hi, kg_lo, kg_hi, QBs);
 }
 
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,

@@ -71,6 +71,9 @@ struct ngd_job {
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
                        uint64_t s0, uint64_t n_sites_chunk, const ngd_score &score, int pairwise_del,
                        double *PA, double *QB, double *PI, unsigned long long *mask);
+// single-image engines: QB of k-groups [kg_lo, kg_hi) from PA, element (i, k) at ngd_frag_off(k, i) - kg_lo * n_ig * 64
+void ngd_launch_qb_range(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *PA, uint64_t kg_lo,
+                         uint64_t kg_hi, double *QBs);
 void ngd_launch_prep_layout(hipStream_t st, const ngd_geom &g, const double *raw, uint64_t s0, uint64_t n_chunk,
                             int in_logscale, int call_geno, double N_thresh, double call_thresh,
                             const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
@@ -108,7 +111,9 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            const double *d_wk, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
                            int exact_shapes, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab,
-                           unsigned long long *d_clk /* [2] or NULL: shader-cycle / constant-rate counter deltas of one wavefront */);
+                           unsigned long long *d_clk /* [2] or NULL: shader-cycle / constant-rate counter deltas of one wavefront */,
+                           uint32_t ks0 = 0 /* the launch covers slices ks0 .. ks0 + n_ks - 1 (multiples of 8) */,
+                           uint32_t resume = 0 /* 1: every block continues from its plane of the slab (a pass in ranges) */);
 
 // accum_em.hip : per-site EM, one thread per pair of a 16x16 tile
 void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,

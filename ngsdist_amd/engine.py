@@ -15,7 +15,7 @@ from . import _lib
 KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4, "em_table": 5}
 # NGD_OPT_* of include/ngsdist_amd.h
 OPTIONS = {"boot_partials": 1, "boot_max_bytes": 2, "boot_wg": 3, "boot_unaligned": 4, "em_batch": 5,
-           "em_spill": 6, "em_spill_bytes": 7}
+           "em_spill": 6, "em_spill_bytes": 7, "single_image_bytes": 8}
 
 # parse_args.cpp:25-27
 DEFAULT_SCORE = (0.0, 0.5, 1.0, 0.5, 0.0, 0.5, 1.0, 0.5, 0.0)
@@ -52,7 +52,8 @@ class Engine:
     gen_dist() over every pair this engine's shard owns."""
 
     def __init__(self, n_ind, n_sites, score=None, pairwise_del=False, indep_geno=True, kernel="auto",
-                 device=-1, shard_rank=0, shard_world=1, variant=0, n_slices=0, wg_target=0, exact_shapes=0):
+                 device=-1, shard_rank=0, shard_world=1, variant=0, n_slices=0, wg_target=0, exact_shapes=0,
+                 single_image=False):
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.NgdConfig()
@@ -65,6 +66,7 @@ class Engine:
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
         # launch geometry, 0 = the engine's defaults (ngd_config)
         cfg.variant, cfg.n_slices, cfg.wg_target, cfg.exact_shapes = int(variant), int(n_slices), int(wg_target), int(exact_shapes)
+        cfg.single_image = int(bool(single_image))  # MFMA kernel: one resident operand image, the other formed per launch
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
         self.n_pairs = n_pairs(self.n_ind)
         _check(self._L.ngd_create(C.byref(cfg), C.byref(self._h)))
@@ -217,7 +219,7 @@ class Engine:
 
     def set_option(self, name, value):
         """plan selection for the replicate loop (ngd_set_option): boot_partials, boot_max_bytes, boot_wg, boot_unaligned,
-        em_batch, em_spill, em_spill_bytes"""
+        em_batch, em_spill, em_spill_bytes, single_image_bytes"""
         _check(self._L.ngd_set_option(self._h, OPTIONS[name], int(value)))
         return self
 

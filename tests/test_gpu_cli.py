@@ -297,6 +297,26 @@ def test_multi_gpu_site_ranges_on_one_device(tmp_path):
         assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+def test_single_image_flag_prints_the_same_bytes(tmp_path):
+    """--single_image (ngd_config.single_image: p resident, q = score . p formed a range of sites at a time): called
+    genotypes print the same bytes (bootstrap, --pairwise_del, site ranges on several engines included); GL data
+    equal to 1e-9; on the EM path the flag changes nothing"""
+    path, lpath, labels = _testA_like(tmp_path)
+    base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345]
+    for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--n_boot_rep", 2, "--n_gpus", 2, "--same_device"]):
+        assert cli(tmp_path, *base, *extra, "--single_image", name="single.dist") == cli(tmp_path, *base, *extra, name="two.dist")
+    n_ind, n_sites = 300, 2000
+    raw = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.1).transpose(1, 0, 2).copy()
+    gl = tmp_path / "g.bin"
+    raw.tofile(str(gl))
+    base = ["--geno", gl, "--probs", "--n_ind", n_ind, "--n_sites", n_sites]
+    for extra in (["--indep_geno", "--pairwise_del"], ["--indep_geno", "--n_boot_rep", "2", "--boot_block_size", "20", "--seed", "3"]):
+        a = cells(cli(tmp_path, *base, *extra, name="two.dist"))
+        b = cells(cli(tmp_path, *base, *extra, "--single_image", name="single.dist"))
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    assert cli(tmp_path, *base, "--single_image", name="single.dist") == cli(tmp_path, *base, name="two.dist")  # EM path
+
+
 def test_fewer_sites_than_one_bootstrap_block(tmp_path):
     """--n_boot_rep with n_sites < --boot_block_size: the reference truncates the replicates to 0 sites
     (ngsDist.cpp:236), visits none and prints 0/0 cells after the full-data matrix"""

@@ -92,6 +92,30 @@ def test_cfg3_streaming_kernel_agrees_on_every_pair(cfg3_mfma):
     assert rel(s, full) < RTOL
 
 
+def test_cfg3_single_image_engine(cfg3_mfma):
+    """ngd_config.single_image at full size: 31 GB resident instead of 51 (p only; q = score . p formed a range of sites
+    at a time beside the kernel), the whole pass equal to rounding, per-block partial sums bit for bit"""
+    full, cnt = cfg3_mfma.run()
+    perm = np.random.default_rng(0).permutation(np.arange(1000, dtype=np.uint64))
+    cfg3_mfma.set_option("boot_partials", 2)
+    try:
+        s_perm, _ = cfg3_mfma.run(perm, 1000)
+    finally:
+        cfg3_mfma.set_option("boot_partials", 1)
+    with N().Engine(1000, 1_000_000, kernel="mfma", single_image=True) as e:
+        e.synth_fill(3)
+        assert e.device_bytes() < 0.65 * cfg3_mfma.device_bytes()
+        s, c = e.run()
+        assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
+        assert np.array_equal(e.run()[0], s)
+        e.set_option("boot_partials", 2)  # (per-block partial sums from the first replicate on, as the fixture's engine has them by now)
+        sp, _ = e.run(perm, 1000)
+        assert np.array_equal(sp, s_perm)
+        e.set_option("boot_partials", 0)
+        sw, _ = e.run(perm, 1000)
+        assert rel(sw, s_perm) < 1e-12
+
+
 def test_cfg4_em_forms_agree_on_every_pair():
     """configs[3] shape (n_ind=1000, EM, JC69) on 20 000 sites, every pair: the table-driven kernel and the per-pair
     fast form vs the form whose iterates are bit-identical to emOptim2.cpp's; plus the oracle on a few pairs."""

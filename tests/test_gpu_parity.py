@@ -481,6 +481,69 @@ def test_mfma_exact_block_forms(n_ind, form):
     assert np.all(owned == 1) and np.array_equal(tot_s, sc)
 
 
+@pytest.mark.parametrize("n_ind,form", [(64, 0), (200, 0), (200, 2), (600, 0), (130, 1)])
+@pytest.mark.parametrize("scratch_bytes", [0, 1])
+def test_mfma_single_image_engine(n_ind, form, scratch_bytes):
+    """ngd_config.single_image (engine.hip launch_accumulate): only p is resident, q = score . p is formed for a range of
+    k-groups at a time (layout.hip k_qb_range, with emit()'s own arithmetic) while the kernel works the range before.
+    Per-block partial sums (blocks of 8 sites and of 6: masked slices) walk ranges of whole slices: the bits of the engine
+    that holds both images.  A whole pass gives every slice a piece of every range (a block adds to its plane of the
+    slab): other sums than one contiguous run of sites per slice -- equal to rounding, checked against the two-image
+    engine and the oracle; called genotypes (exact arithmetic) bit for bit.  scratch_bytes 1: the smallest ranges."""
+    n_sites = 5000
+    p = O.synth_indmajor(77 + n_ind, n_ind, n_sites, miss_frac=0.1)
+    rng = np.random.default_rng(n_ind)
+    pc = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(pc, rng.integers(0, 3, size=(n_ind, n_sites))[..., None], 1.0, axis=2)
+    out = []
+    for single in (False, True):
+        with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single) as e:
+            if single and scratch_bytes:
+                e.set_option("single_image_bytes", scratch_bytes)
+            e.upload_ind_major(p).commit()
+            r = [e.run()]
+            for B, partials in ((8, 2), (6, 2), (7, 0)):  # (2: partials whatever their slab costs -- the same plan in both engines)
+                m = N().Taus(B + n_ind).block_map(n_sites // B)
+                e.set_option("boot_partials", partials)
+                r.append(e.run(m, B))
+            r.append(e.run())
+            nbytes = e.device_bytes()
+        with N().Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form, single_image=single) as e:
+            if single and scratch_bytes:
+                e.set_option("single_image_bytes", scratch_bytes)
+            e.upload_ind_major(pc).commit()
+            e.set_option("boot_partials", 0)
+            r.append(e.run())
+            r.append(e.run(N().Taus(7 + n_ind).block_map(n_sites // 7), 7))
+        out.append((r, nbytes))
+    (two, bytes_two), (one, bytes_one) = out
+    # (bytes_*: a data set this small is two ranges, i.e. no saving -- tests/test_gpu_fullsize.py checks it at cfg 3)
+    for k in (1, 2, 5, 6):
+        assert np.array_equal(two[k][0], one[k][0]) and np.array_equal(two[k][1], one[k][1]), k
+    assert np.array_equal(one[0][0], one[4][0])  # run to run
+    for k in (0, 3):
+        assert np.array_equal(two[k][1], one[k][1]) and rel_err(one[k][0], two[k][0]) < RTOL
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    assert np.array_equal(one[0][1], co) and rel_err(one[0][0], so) < RTOL
+    m = N().Taus(7 + n_ind).block_map(n_sites // 7)
+    sb, cb = O.all_pairs(p, pairwise_del=True, site_src=O.boot_site_src(m, 7), n_sites=n_sites // 7 * 7, n_threads=8)
+    assert np.array_equal(one[3][1], cb) and rel_err(one[3][0], sb) < RTOL
+
+
+def test_single_image_is_an_mfma_engine_option():
+    """other kernels hold one image anyway: the flag is accepted and changes nothing; the option that sizes the
+    scratch is refused without it"""
+    with N().Engine(40, 512, kernel="mfma") as e:
+        with pytest.raises(N().NgdError):
+            e.set_option("single_image_bytes", 1 << 20)
+    p = O.synth_indmajor(5, 40, 512)
+    with N().Engine(40, 512, kernel="stream", single_image=True) as e:
+        s, c = e.upload_ind_major(p).commit().run()
+    with N().Engine(40, 512, kernel="stream") as e:
+        s2, c2 = e.upload_ind_major(p).commit().run()
+    assert np.array_equal(s, s2) and np.array_equal(c, c2)
+
+
 @pytest.mark.parametrize("kernel", INDEP_KERNELS + EM_KERNELS)
 def test_deterministic_run_to_run(kernel):
     """results must not depend on the run (slabs summed in fixed order, no floating-point atomics) --

@@ -34,6 +34,12 @@ for case in range(first, first + n_cases):
     spill_bytes = int(rng.choice([0, 0, 1 << 20, 3 << 20])) if em_spill else 0  # a few k-groups of terms per chunk
     geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 7)) if kernel == "mfma" else 0,
                 variant=int(rng.integers(0, 5)) if kernel == "em_table" else 0)
+    # (drawn from a generator of their own: the cases of earlier rounds keep their shapes)
+    rng_si = np.random.default_rng(7_000_000 + case)
+    single = kernel == "mfma" and bool(rng_si.integers(0, 2))  # ngd_config.single_image; the scratch: 4 GB or the smallest ranges
+    single_bytes = int(rng_si.choice([0, 1, 1 << 20])) if single else 0
+    if single:
+        geom["single_image"] = True
     score = O.score_matrix(bool(rng.integers(0, 2)))
     model = int(rng.integers(0, 3))
     p = O.synth_indmajor(1000 + case, n_ind, n_sites, miss_frac=miss)
@@ -43,7 +49,7 @@ for case in range(first, first + n_cases):
     n_eff = n_sites - n_sites % B
     t = N.Taus(case)
     maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
-    tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, em_spill, spill_bytes, geom)
+    tag = (case, kernel, n_ind, n_sites, pdel, miss, B, n_rep, partials, em_batch, em_spill, spill_bytes, geom, single_bytes)
     big = False
     mode = int(rng.integers(0, 3))  # 0: one engine; 1: site ranges (partial multiplicities); 2: pair-tile shards
     tag = tag + (("one", "site ranges", "pair tiles")[mode],)
@@ -77,6 +83,8 @@ for case in range(first, first + n_cases):
                 with N.Engine(n_ind, hi - lo, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom, **kw) as e:
                     e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
                     e.set_option("em_spill", em_spill).set_option("em_spill_bytes", spill_bytes)
+                    if single:
+                        e.set_option("single_image_bytes", single_bytes)
                     e.upload_ind_major(sub).commit()
                     s0, c0 = e.run()
                     S[0] += s0
@@ -89,6 +97,8 @@ for case in range(first, first + n_cases):
           with N.Engine(n_ind, n_sites, score=score, pairwise_del=pdel, indep_geno=indep, kernel=kernel, **geom) as e:
             e.set_option("boot_partials", partials).set_option("em_batch", em_batch)
             e.set_option("em_spill", em_spill).set_option("em_spill_bytes", spill_bytes)
+            if single:
+                e.set_option("single_image_bytes", single_bytes)
             e.upload_ind_major(p).commit()
             S, Cn = e.run_job(maps, B)
         for m in sorted({0, n_rep // 2, n_rep}):

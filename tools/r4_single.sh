@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 4: the single-image engine -- parity tests, then cfg 3 with and without it (serial headline region only), and
+# with other sizes of the scratch the second image is formed in; A/B libraries (tools/build_variant.sh tags) as arguments
+set -e
+mkdir -p gpurun_out
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "single_image" > gpurun_out/r4_single_tests.log 2>&1 || { tail -30 gpurun_out/r4_single_tests.log; exit 1; }
+tail -2 gpurun_out/r4_single_tests.log
+line() { python3 - "$1" <<'PY'
+import json, sys
+f = sys.argv[1]
+j = json.loads(open("gpurun_out/%s.json" % f).read().strip().splitlines()[-1])
+print(f, "%.2f ms/step" % j["ms_per_step"], "frac %.3f" % j["roofline"]["frac"], "%.1f GB" % (j["config"]["device_bytes"] / 1e9), j.get("valid"))
+PY
+}
+B="timeout -k 10 300 python3 bench.py --workload cfg3 --no_cpu --steps 10 --warmup 3"
+$B > gpurun_out/r4_two_cfg3.json 2> gpurun_out/r4_two_cfg3.err
+line r4_two_cfg3
+$B --single_image > gpurun_out/r4_single_cfg3.json 2> gpurun_out/r4_single_cfg3.err
+line r4_single_cfg3
+for gb in 1 2 8 12; do
+  $B --single_image --single_image_gb $gb > gpurun_out/r4_single_cfg3_${gb}gb.json 2> gpurun_out/r4_single_cfg3_${gb}gb.err
+  line r4_single_cfg3_${gb}gb
+done
+for tag in "$@"; do
+  NGSDIST_AMD_LIB=ngsdist_amd/libngsdist_amd.so.$tag $B --single_image > gpurun_out/r4_single_cfg3_$tag.json 2> gpurun_out/r4_single_cfg3_$tag.err
+  line r4_single_cfg3_$tag
+done
