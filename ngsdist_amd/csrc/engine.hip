@@ -63,7 +63,10 @@ struct ngd_engine {
   int em_shape = 0;  // accum_em_table.hip: workgroup shape
   unsigned long long *d_emcnt = nullptr;  // [4] work counters of the table-driven EM kernel + its clock counters
   unsigned long long em_counts[2] = {0, 0};  // ... of the last run
-  unsigned long long *d_clk = nullptr;  // [2] MFMA kernel: shader-cycle / constant-rate counter deltas of one wavefront
+  // [2] MFMA kernel: shader-cycle / constant-rate counter deltas of one wavefront.  Pinned HOST memory mapped into the
+  // device's address space: the wavefront's two stores cross PCIe, and reading them after the stream has been waited for
+  // is a plain load (a 16-byte hipMemcpy per pass was 10 us of a 350 us job at cfg 2)
+  unsigned long long *d_clk = nullptr, *h_clk = nullptr;  // (the device's and the host's pointer to it)
   double clk_mhz = 0;                   // shader clock of the last accumulation launch (0: not sampled)
   double wall_khz = 100000.0;           // rate of the constant counter (hipDeviceAttributeWallClockRate)
   // MFMA kernel: per-wavefront 64x64 jobs, 4 per workgroup; "tri" = blocks on the diagonal
@@ -195,7 +198,7 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag, e->d_clk};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -203,6 +206,7 @@ void ngd_destroy(ngd_engine *e) {
     if (e->draw[b]) hipFree(e->draw[b]);
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
   }
+  if (e->h_clk) hipHostFree(e->h_clk);
   if (e->d_nan) hipFree(e->d_nan);
   if (e->h_mult) hipHostFree(e->h_mult);
   for (auto &v : e->ev)
@@ -536,7 +540,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
-    TRY(dev_alloc(e, &e->d_clk, 2, true));
+    if (hipHostMalloc((void **)&e->h_clk, 2 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&e->d_clk, e->h_clk, 0) != hipSuccess)
+      return bail(fail(NGD_E_NOMEM, "ngd_create: no pinned host memory for the clock sample"));
+    e->h_clk[0] = e->h_clk[1] = 0;
     if (e->single_image) {
       // scratch for QB: one range of a whole pass (launch_accumulate(); partial-sum passes grow it if a bootstrap
       // block is longer)
@@ -803,10 +810,9 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
       hipMemsetAsync(e->d_emcnt, 0, sizeof(c), e->st);
     }
   }
-  if (e->d_clk && launches) {
-    unsigned long long c[2] = {0, 0};
-    if (hipMemcpy(c, e->d_clk, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c[1])
-      e->clk_mhz = (double)c[0] / (double)c[1] * e->wall_khz * 1e-3;
+  if (e->d_clk && launches) {  // (the stream is idle: the sampling wavefront's stores have landed)
+    const unsigned long long c0 = ((volatile unsigned long long *)e->h_clk)[0], c1 = ((volatile unsigned long long *)e->h_clk)[1];
+    if (c1) e->clk_mhz = (double)c0 / (double)c1 * e->wall_khz * 1e-3;
   }
   float ms[4] = {0, 0, 0, 0};
   hipEventElapsedTime(&ms[0], e->ev[0], e->ev[4]);
