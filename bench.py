@@ -648,6 +648,10 @@ def main():
                 "traffic": None, "ms_per_launch": acc_mean_ms,
                 "algorithmic": "%.0f FP64 flop per pair-site x %.4g pair-sites per launch"
                                % (FLOPS_PER_PAIR_SITE, pair_sites_per_launch_all / world)}
+        if args.single_image:
+            roof["note"] = ("single-image engine: a pass is one launch of the kernel per range of the second operand image "
+                            "plus the kernel that forms the range (k_qb_range, HBM-bound); ms_per_launch is the whole "
+                            "accumulation phase of a pass, frac the pass's flops against it")
         sb = BYTES_PER_PAIR_SITE * pair_sites_per_launch_all / world / t_acc / 1e9
         roof["stream_model"] = {"bound": "hbm", "achieved": sb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": sb / PEAK_HBM_GBS,
