@@ -85,6 +85,8 @@ def main():
                     help="ngd_config.single_image: hold one operand image, form the other per launch (memory for time)")
     ap.add_argument("--single_image_gb", type=float, default=0.0,
                     help="with --single_image: GB of the second image formed at a time (NGD_OPT_SINGLE_IMAGE_BYTES; 0 = 4)")
+    ap.add_argument("--second_image_gb", type=float, default=0.0,
+                    help="with --single_image: GB of the second image kept resident all the same (ngd_config.second_image_mib)")
     ap.add_argument("--exact_shapes", type=int, default=0,
                     help="ngd_config.exact_shapes: the MFMA kernel's block form (0 = the engine's choice; experiments)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
@@ -192,13 +194,13 @@ def main():
         lo = (n_units * rank // world) * unit
         hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
         eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       exact_shapes=args.exact_shapes, single_image=args.single_image)
+                       exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image else 0)
         eng.synth_fill(W["seed"], args.miss_frac, site0=lo)
         blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
     else:
         lo, hi = 0, n_sites
         eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes, single_image=args.single_image)
+                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image else 0)
         eng.synth_fill(W["seed"], args.miss_frac)
     if args.single_image and args.single_image_gb > 0:
         eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
@@ -766,7 +768,7 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
-                   "device_bytes": eng.device_bytes(), "single_image": bool(args.single_image),
+                   "device_bytes": eng.device_bytes(), "single_image": bool(args.single_image), "second_image_gb": args.second_image_gb if args.single_image else None,
                    "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
                                "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
                                "device buffers, copied to pinned host memory"),

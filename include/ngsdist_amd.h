@@ -78,10 +78,12 @@ typedef struct ngd_config {
                          /* (auto: when n_ind padded to 128 is at most 384)                            */
   uint32_t single_image; /* NGD_KERNEL_MFMA: 1 = hold ONE operand image (p) and form the score-weighted one  */
                          /* (q = score . p, ngsDist.cpp:351-353 regrouped) for a range of sites at a time,  */
-                         /* before the launch that reads it: 31 GB instead of 51 for 1000 x 1e6 -- twice the  */
+                         /* before the launch that reads it: 30 GB instead of 51 for 1000 x 1e6 -- twice the  */
                          /* sites per engine -- for a quarter more time; sums equal to rounding, per-block   */
                          /* partial sums bit for bit                                   */
-  uint32_t reserved[1];  /* must be zero                                                               */
+  uint32_t second_image_mib; /* single_image engines: MiB of the second image kept resident all the same, from  */
+                         /* the first site on (what the device has to spare): only the rest is formed range  */
+                         /* by range, and the extra time shrinks in proportion                               */
 } ngd_config;
 
 /* Per-run device timings (HIP events on the engine's stream). */

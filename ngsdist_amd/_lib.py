@@ -29,7 +29,7 @@ class NgdConfig(C.Structure):
         ("wg_target", C.c_uint32),
         ("exact_shapes", C.c_uint32),
         ("single_image", C.c_uint32),
-        ("reserved", C.c_uint32 * 1),
+        ("second_image_mib", C.c_uint32),
     ]
 
 

@@ -46,6 +46,8 @@ struct ngd_engine {
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
   // ngd_config.single_image (MFMA kernel): QB is not resident; a launch forms it for a range of k-groups at a time
   bool single_image = false;
+  double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
+  uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
   uint64_t qb_chunk_kg = 0;     // k-groups a range may span (NGD_OPT_SINGLE_IMAGE_BYTES)
   uint64_t qb_chunk_elems = 0;  // capacity of the scratch
@@ -196,7 +198,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
+  void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
   for (void *p : ptrs)
@@ -223,9 +225,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // tile lists index groups of 16 individuals with 16 bits; what bounds n_ind in practice is device memory (two
   // n_pairs-long result arrays + one n_pad x n_pad plane per slice), checked below before any list is built
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
-  for (uint32_t r : cfg->reserved)
-    if (r) return fail(NGD_E_INVALID, "ngd_create: reserved fields must be zero");
   if (cfg->single_image > 1) return fail(NGD_E_INVALID, "ngd_create: single_image is 0 or 1");
+  if (cfg->second_image_mib && !cfg->single_image)
+    return fail(NGD_E_INVALID, "ngd_create: second_image_mib belongs to single_image engines");
   if (cfg->exact_shapes > 6)
     return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
                                "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup) or 6 (5 with operands "
@@ -482,7 +484,12 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } else {
     TRY(dev_alloc(e, &e->PA, frag_elems, true));
     e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image;
+    if (e->single_image) {  // ... and as much of the second image as the caller has memory to spare for
+      e->qb_res_kg = std::min<uint64_t>(g.n_kg, ((uint64_t)cfg->second_image_mib << 20) / ((uint64_t)g.n_ig * 64 * 8));
+      if (e->qb_res_kg == g.n_kg) { e->single_image = false; e->qb_res_kg = 0; }  // all of it: the two-image engine
+    }
     if (kernel == NGD_KERNEL_MFMA && !e->single_image) TRY(dev_alloc(e, &e->QB, frag_elems, true));
+    if (e->qb_res_kg) TRY(dev_alloc(e, &e->QB_res, (e->qb_res_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64, false));
   }
   if (cfg->pairwise_del) {
     TRY(dev_alloc(e, &e->mask, g.n_ind * (uint64_t)g.n_words, true));
@@ -524,7 +531,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       // A single-image engine walks the pass in ranges (launch_accumulate()): every launch has all the slices, and every
       // block adds to its plane of the slab at the end of each ([measured] cfg 3, 248 slices, 12 ranges: +0.53 ms per
       // launch, 2.1 us per slice -- 2.7 reductions' worth).  Fewer slices then: as few as fill their rounds.
-      const uint64_t qb_ranges = e->single_image ? std::max<uint64_t>(1, (g.n_kg + single_image_span(g) - 1) / single_image_span(g)) : 0;
+      const uint64_t qb_ranges =
+          e->single_image ? (g.n_kg - e->qb_res_kg + single_image_span(g) - 1) / single_image_span(g) + (e->qb_res_kg ? 1 : 0) : 0;
       const double per_slice_s = reduce_s_per_slice * (1.0 + 2.7 * (double)qb_ranges);
       double best = 1e30;
       uint64_t best_ks = ks;
@@ -549,7 +557,8 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       // block is longer)
       e->qb_chunk_kg = single_image_span(g);
       uint64_t n_ranges = 0;
-      const uint64_t range_kg = std::min<uint64_t>(g.n_kg, qb_piece(g.n_kg, e->n_ks, e->qb_chunk_kg, &n_ranges) * e->n_ks);
+      const uint64_t rest_kg = g.n_kg - e->qb_res_kg;  // (what is not resident: ngd_config.second_image_mib)
+      const uint64_t range_kg = std::min<uint64_t>(rest_kg, qb_piece(rest_kg, e->n_ks, e->qb_chunk_kg, &n_ranges) * e->n_ks);
       e->qb_chunk_elems = (range_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64;
       TRY(dev_alloc(e, &e->qb_chunk, e->qb_chunk_elems, false));
     }
@@ -704,6 +713,9 @@ int ngd_commit(ngd_engine *e) {
     e->dev_bytes -= e->staging_sites * e->g.n_ind * 24;
     e->staging = nullptr;
   }
+  if (e->QB_res)  // single-image engine: the part of the second image it keeps (stream order: before any pass)
+    ngd_launch_qb_range(e->st, e->g, e->sc, e->PA, 0, std::min<uint64_t>(e->qb_res_kg + NGD_KG_TAIL, e->g.n_kg + NGD_KG_TAIL),
+                        e->QB_res);
   e->committed = true;
   return NGD_OK;
 }
@@ -754,14 +766,30 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
         auto slice_kg1 = [&](uint64_t ks) {
           return std::min<uint64_t>(kg_lim, k_per_slice ? ((ks + 1) * k_per_slice + 3) >> 2 : (ks + 1) * per_slice);
         };
+        const double *wsel = k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr);
+        // what the engine keeps of the second image (its first qb_res_kg k-groups, ngd_config.second_image_mib) is read
+        // where it lies: one launch over that part of a whole pass, or over the slices that end inside it
+        const uint64_t res = std::min<uint64_t>(e->qb_res_kg, kg_lim);
+        uint32_t ks_first = 0;
+        if (res && whole_pass) {
+          const uint64_t piece_r = std::max<uint64_t>(4, ((res + n_ks - 1) / n_ks + 3) / 4 * 4);
+          ngd_launch_accum_mfma(e->st, g, e->PA, e->QB_res, wsel, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks,
+                                piece_r, res, 0, 0, slab, e->d_clk, 0, 0);
+        } else if (res) {
+          while (ks_first + 8 <= n_ks && slice_kg1(ks_first + 7) <= res && slice_kg0(ks_first + 7) < kg_lim) ks_first += 8;
+          if (ks_first)
+            ngd_launch_accum_mfma(e->st, g, e->PA, e->QB_res, wsel, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves,
+                                  ks_first, per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, 0);
+        }
+        const uint64_t rest0 = whole_pass ? res : 0;  // a whole pass goes on from here
         uint64_t piece = 0, n_ranges = 0;
-        if (whole_pass) piece = qb_piece(kg_lim, n_ks, span, &n_ranges);
+        if (whole_pass && kg_lim > rest0) piece = qb_piece(kg_lim - rest0, n_ks, span, &n_ranges);
         uint32_t r = 0;
-        for (uint32_t ks0 = 0; whole_pass ? r < n_ranges : ks0 < n_ks; r++) {
+        for (uint32_t ks0 = ks_first; whole_pass ? r < n_ranges : ks0 < n_ks; r++) {
           uint32_t n = 8;
           uint64_t lo, hi;
           if (whole_pass) {
-            lo = std::min<uint64_t>((uint64_t)r * piece * n_ks, kg_lim);
+            lo = std::min<uint64_t>(rest0 + (uint64_t)r * piece * n_ks, kg_lim);
             hi = std::min<uint64_t>(lo + piece * n_ks, kg_lim);
           } else {
             while (ks0 + n < n_ks && slice_kg1(ks0 + n + 7) - slice_kg0(ks0) <= span && slice_kg0(ks0 + n) < kg_lim) n += 8;
@@ -778,10 +806,10 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
             if (rc) return rc;
           }
           ngd_launch_qb_range(e->st, g, e->sc, e->PA, lo, std::min<uint64_t>(hi + NGD_KG_TAIL, g.n_kg + NGD_KG_TAIL), e->qb_chunk);
-          const double *wsel = k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr);
           if (whole_pass)
             ngd_launch_accum_mfma(e->st, g, e->PA + lo * kstride, e->qb_chunk, wsel ? wsel + lo * 4 : nullptr, nullptr, e->d_jobs,
-                                  e->n_wg, e->exact_shapes, e->wg_waves, n_ks, piece, hi - lo, 0, 0, slab, e->d_clk, 0, r > 0);
+                                  e->n_wg, e->exact_shapes, e->wg_waves, n_ks, piece, hi - lo, 0, 0, slab, e->d_clk, 0,
+                                  r > 0 || res > 0);
           else
             ngd_launch_accum_mfma(e->st, g, e->PA, e->qb_chunk - lo * kstride, wsel, nullptr, e->d_jobs, e->n_wg,
                                   e->exact_shapes, e->wg_waves, n, per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, ks0);
@@ -1505,7 +1533,8 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       break;
     case NGD_OPT_EM_SPILL_BYTES: e->opt_em_spill_bytes = value; break;
     case NGD_OPT_SINGLE_IMAGE_BYTES:
-      if (!e->single_image) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_SINGLE_IMAGE_BYTES needs ngd_config.single_image");
+      if (!e->cfg.single_image) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_SINGLE_IMAGE_BYTES needs ngd_config.single_image");
+      if (!e->single_image) break;  // (another kernel, or second_image_mib holds the whole second image: nothing is formed)
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
       break;
     default: return fail(NGD_E_INVALID, "ngd_set_option: unknown option");

@@ -24,7 +24,8 @@
 //    genotypes, <= 1e-12 relative otherwise), --device D (first device), --same_device (every range on --device: a
 //    rehearsal on one GPU), --max_device_bytes B (device budget; a data set above it goes through in several ranges
 //    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful, --single_image (--indep_geno on the MFMA
-//    kernel: ngd_config.single_image -- half the device memory per site, so twice the sites per range, a quarter slower),
+//    kernel: ngd_config.single_image -- half the device memory per site, so twice the sites per range, up to a quarter
+//    slower: what the device budget leaves is given to the first part of the second image, ngd_config.second_image_mib),
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -959,6 +960,9 @@ int main(int argc, char **argv) {
   int n_dev = ngd_device_count();
   if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
   if (p.device + (p.same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
+  // (--single_image: what the device budget leaves after the one image is given to the first part of the second,
+  // ngd_config.second_image_mib -- half of it when bootstrap partial sums will want room too; set by the plan below)
+  uint64_t plan_budget = 0, plan_fixed = 0, plan_per_site = 0, plan_n_pad = 0;
   auto make_engine = [&](Engine &eng, uint64_t n_sites_part, int dev_index) {
     ngd_config cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -970,6 +974,12 @@ int main(int argc, char **argv) {
     cfg.device = p.same_device ? p.device : p.device + dev_index;
     cfg.kernel = p.kernel;
     cfg.single_image = p.single_image ? 1 : 0;  // (means something to the MFMA kernel only)
+    if (p.single_image && plan_budget) {
+      const uint64_t need = plan_fixed + plan_per_site * n_sites_part;
+      uint64_t spare = plan_budget > need ? plan_budget - need : 0;
+      if (p.n_boot_rep) spare /= 2;
+      cfg.second_image_mib = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(spare, 24 * plan_n_pad * n_sites_part) >> 20, 0xffffffffu);
+    }
     int rc = ngd_create(&cfg, &eng.h);
     if (rc) die_engine("ngd_create", rc);
   };
@@ -993,6 +1003,7 @@ int main(int argc, char **argv) {
   if (p.same_device) dev_free /= (uint64_t)p.n_gpus;  // the rehearsal's ranges share one device
   const uint64_t budget = p.max_device_bytes ? p.max_device_bytes : dev_free / 100 * 85;
   const bool in_parts = p.n_gpus > 1 || fixed + per_site * p.n_sites > budget;
+  plan_budget = budget; plan_fixed = fixed; plan_per_site = per_site; plan_n_pad = n_pad;
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];

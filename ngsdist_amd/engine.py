@@ -53,7 +53,7 @@ class Engine:
 
     def __init__(self, n_ind, n_sites, score=None, pairwise_del=False, indep_geno=True, kernel="auto",
                  device=-1, shard_rank=0, shard_world=1, variant=0, n_slices=0, wg_target=0, exact_shapes=0,
-                 single_image=False):
+                 single_image=False, second_image_bytes=0):
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.NgdConfig()
@@ -67,6 +67,7 @@ class Engine:
         # launch geometry, 0 = the engine's defaults (ngd_config)
         cfg.variant, cfg.n_slices, cfg.wg_target, cfg.exact_shapes = int(variant), int(n_slices), int(wg_target), int(exact_shapes)
         cfg.single_image = int(bool(single_image))  # MFMA kernel: one resident operand image, the other formed per launch
+        cfg.second_image_mib = int(second_image_bytes) >> 20  # ... except this much of it, kept resident all the same
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
         self.n_pairs = n_pairs(self.n_ind)
         _check(self._L.ngd_create(C.byref(cfg), C.byref(self._h)))

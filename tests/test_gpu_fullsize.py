@@ -104,7 +104,7 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         cfg3_mfma.set_option("boot_partials", 1)
     with N().Engine(1000, 1_000_000, kernel="mfma", single_image=True) as e:
         e.synth_fill(3)
-        assert e.device_bytes() < 0.65 * cfg3_mfma.device_bytes()
+        assert e.device_bytes() < 31e9  # (both images: 51.3 GB)
         s, c = e.run()
         assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
         assert np.array_equal(e.run()[0], s)
@@ -114,6 +114,15 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         e.set_option("boot_partials", 0)
         sw, _ = e.run(perm, 1000)
         assert rel(sw, s_perm) < 1e-12
+    # ... and with 10 GB of the second image kept resident (ngd_config.second_image_mib): the same results
+    with N().Engine(1000, 1_000_000, kernel="mfma", single_image=True, second_image_bytes=10 << 30) as e:
+        e.synth_fill(3)
+        assert 38e9 < e.device_bytes() < 42e9  # (29.7 GB + 10.7; both images: 51.3)
+        s, c = e.run()
+        assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
+        e.set_option("boot_partials", 2)
+        sp, _ = e.run(perm, 1000)
+        assert np.array_equal(sp, s_perm)
 
 
 def test_cfg4_em_forms_agree_on_every_pair():

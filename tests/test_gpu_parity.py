@@ -482,14 +482,15 @@ def test_mfma_exact_block_forms(n_ind, form):
 
 
 @pytest.mark.parametrize("n_ind,form", [(64, 0), (200, 0), (200, 2), (600, 0), (130, 1)])
-@pytest.mark.parametrize("scratch_bytes", [0, 1])
-def test_mfma_single_image_engine(n_ind, form, scratch_bytes):
+@pytest.mark.parametrize("scratch_bytes,resident", [(0, 0), (1, 0), (1, 6 << 20)])
+def test_mfma_single_image_engine(n_ind, form, scratch_bytes, resident):
     """ngd_config.single_image (engine.hip launch_accumulate): only p is resident, q = score . p is formed for a range of
     k-groups at a time (layout.hip k_qb_range, with emit()'s own arithmetic) while the kernel works the range before.
     Per-block partial sums (blocks of 8 sites and of 6: masked slices) walk ranges of whole slices: the bits of the engine
     that holds both images.  A whole pass gives every slice a piece of every range (a block adds to its plane of the
     slab): other sums than one contiguous run of sites per slice -- equal to rounding, checked against the two-image
-    engine and the oracle; called genotypes (exact arithmetic) bit for bit.  scratch_bytes 1: the smallest ranges."""
+    engine and the oracle; called genotypes (exact arithmetic) bit for bit.  scratch_bytes 1: the smallest ranges;
+    resident: ngd_config.second_image_mib, the first part of q kept on the device and read where it lies."""
     n_sites = 5000
     p = O.synth_indmajor(77 + n_ind, n_ind, n_sites, miss_frac=0.1)
     rng = np.random.default_rng(n_ind)
@@ -497,7 +498,8 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes):
     np.put_along_axis(pc, rng.integers(0, 3, size=(n_ind, n_sites))[..., None], 1.0, axis=2)
     out = []
     for single in (False, True):
-        with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single) as e:
+        with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single,
+                        second_image_bytes=resident if single else 0) as e:
             if single and scratch_bytes:
                 e.set_option("single_image_bytes", scratch_bytes)
             e.upload_ind_major(p).commit()
@@ -508,7 +510,8 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes):
                 r.append(e.run(m, B))
             r.append(e.run())
             nbytes = e.device_bytes()
-        with N().Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form, single_image=single) as e:
+        with N().Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form, single_image=single,
+                        second_image_bytes=resident if single else 0) as e:
             if single and scratch_bytes:
                 e.set_option("single_image_bytes", scratch_bytes)
             e.upload_ind_major(pc).commit()
@@ -532,7 +535,18 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes):
 
 def test_single_image_is_an_mfma_engine_option():
     """other kernels hold one image anyway: the flag is accepted and changes nothing; the option that sizes the
-    scratch is refused without it"""
+    scratch is refused without it, second_image_mib too; with room for the whole second image the engine is the
+    two-image one, bit for bit"""
+    p = O.synth_indmajor(6, 150, 3000, miss_frac=0.05)
+    m = N().Taus(3).block_map(3000 // 5)
+    res = []
+    for kw in ({}, dict(single_image=True, second_image_bytes=1 << 30)):
+        with N().Engine(150, 3000, kernel="mfma", pairwise_del=True, **kw) as e:
+            e.upload_ind_major(p).commit()
+            res.append((e.run(), e.run(m, 5), e.device_bytes()))
+    assert all(np.array_equal(a, b) for k in (0, 1) for a, b in zip(res[0][k], res[1][k])) and res[0][2] == res[1][2]
+    with pytest.raises(N().NgdError):
+        N().Engine(40, 512, kernel="mfma", second_image_bytes=1 << 20)
     with N().Engine(40, 512, kernel="mfma") as e:
         with pytest.raises(N().NgdError):
             e.set_option("single_image_bytes", 1 << 20)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 4: the single-image engine -- parity tests, then cfg 3 with and without it (serial headline region only), and
-# with other sizes of the scratch the second image is formed in; A/B libraries (tools/build_variant.sh tags) as arguments
+# round 4: the single-image engine -- parity tests, then cfg 3 with and without it (serial headline region only), with
+# other sizes of the scratch the second image is formed in, and with part of the second image kept resident
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "single_image" > gpurun_out/r4_single_tests.log 2>&1 || { tail -30 gpurun_out/r4_single_tests.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_abi.py -x -q -m gpu -k "single_image or abi" > gpurun_out/r4_single_tests.log 2>&1 || { tail -30 gpurun_out/r4_single_tests.log; exit 1; }
 tail -2 gpurun_out/r4_single_tests.log
 line() { python3 - "$1" <<'PY'
 import json, sys
@@ -17,11 +17,11 @@ $B > gpurun_out/r4_two_cfg3.json 2> gpurun_out/r4_two_cfg3.err
 line r4_two_cfg3
 $B --single_image > gpurun_out/r4_single_cfg3.json 2> gpurun_out/r4_single_cfg3.err
 line r4_single_cfg3
-for gb in 1 2 8 12; do
+for gb in ${SCRATCH_GB:-}; do
   $B --single_image --single_image_gb $gb > gpurun_out/r4_single_cfg3_${gb}gb.json 2> gpurun_out/r4_single_cfg3_${gb}gb.err
   line r4_single_cfg3_${gb}gb
 done
-for tag in "$@"; do
-  NGSDIST_AMD_LIB=ngsdist_amd/libngsdist_amd.so.$tag $B --single_image > gpurun_out/r4_single_cfg3_$tag.json 2> gpurun_out/r4_single_cfg3_$tag.err
-  line r4_single_cfg3_$tag
+for gb in ${RESIDENT_GB:-6 12 18 23}; do
+  $B --single_image --second_image_gb $gb > gpurun_out/r4_single_cfg3_res${gb}.json 2> gpurun_out/r4_single_cfg3_res${gb}.err
+  line r4_single_cfg3_res${gb}
 done
