@@ -81,8 +81,9 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
-    ap.add_argument("--single_image", action="store_true",
-                    help="ngd_config.single_image: hold one operand image, form the other per launch (memory for time)")
+    ap.add_argument("--single_image", type=int, nargs="?", const=1, default=0,
+                    help="ngd_config.single_image: hold one operand image -- 1: the other formed a range of sites at a time "
+                         "(memory for time), 2: both operands from one image in congruent coordinates")
     ap.add_argument("--single_image_gb", type=float, default=0.0,
                     help="with --single_image: GB of the second image formed at a time (NGD_OPT_SINGLE_IMAGE_BYTES; 0 = 4)")
     ap.add_argument("--second_image_gb", type=float, default=0.0,
@@ -194,15 +195,15 @@ def main():
         lo = (n_units * rank // world) * unit
         hi = (n_units * (rank + 1) // world) * unit if rank + 1 < world else n_sites
         eng = N.Engine(n_ind, hi - lo, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image else 0)
+                       exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image == 1 else 0)
         eng.synth_fill(W["seed"], args.miss_frac, site0=lo)
         blk_lo, blk_hi = lo // W["block"], min(hi, n_eff) // W["block"]
     else:
         lo, hi = 0, n_sites
         eng = N.Engine(n_ind, n_sites, indep_geno=W["indep"], kernel=kernel, device=local_rank, pairwise_del=pdel,
-                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image else 0)
+                       shard_rank=0 if by_reps else rank, shard_world=1 if by_reps else world, exact_shapes=args.exact_shapes, single_image=args.single_image, second_image_bytes=int(args.second_image_gb * 2**30) if args.single_image == 1 else 0)
         eng.synth_fill(W["seed"], args.miss_frac)
-    if args.single_image and args.single_image_gb > 0:
+    if args.single_image == 1 and args.single_image_gb > 0:
         eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
@@ -650,7 +651,7 @@ def main():
                 "traffic": None, "ms_per_launch": acc_mean_ms,
                 "algorithmic": "%.0f FP64 flop per pair-site x %.4g pair-sites per launch"
                                % (FLOPS_PER_PAIR_SITE, pair_sites_per_launch_all / world)}
-        if args.single_image:
+        if args.single_image == 1:
             roof["note"] = ("single-image engine: a pass is one launch of the kernel per range of the second operand image "
                             "plus the kernel that forms the range (k_qb_range, HBM-bound); ms_per_launch is the whole "
                             "accumulation phase of a pass, frac the pass's flops against it")
@@ -768,7 +769,7 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
-                   "device_bytes": eng.device_bytes(), "single_image": bool(args.single_image), "second_image_gb": args.second_image_gb if args.single_image else None,
+                   "device_bytes": eng.device_bytes(), "single_image": args.single_image, "second_image_gb": args.second_image_gb if args.single_image == 1 else None,
                    "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
                                "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
                                "device buffers, copied to pinned host memory"),

@@ -76,14 +76,22 @@ typedef struct ngd_config {
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 / 3 = always issue only the MFMA tiles a     */
                          /* block needs, in blocks of up to 4 x 4 / 2 x 4 tiles of 16 x 16 pairs       */
                          /* (auto: when n_ind padded to 128 is at most 384)                            */
-  uint32_t single_image; /* NGD_KERNEL_MFMA: 1 = hold ONE operand image (p) and form the score-weighted one  */
-                         /* (q = score . p, ngsDist.cpp:351-353 regrouped) for a range of sites at a time,  */
-                         /* before the launch that reads it: 30 GB instead of 51 for 1000 x 1e6 -- twice the  */
-                         /* sites per engine -- for a quarter more time; sums equal to rounding, per-block   */
-                         /* partial sums bit for bit                                   */
-  uint32_t second_image_mib; /* single_image engines: MiB of the second image kept resident all the same, from  */
-                         /* the first site on (what the device has to spare): only the rest is formed range  */
-                         /* by range, and the extra time shrinks in proportion                               */
+  uint32_t single_image; /* NGD_KERNEL_MFMA holds two operand images (p and q = score . p, ngsDist.cpp:351-353    */
+                         /* regrouped): 48 bytes per (padded individual, site).  ONE image, i.e. twice the sites   */
+                         /* per engine (1000 x 1e6: 27-30 GB instead of 51):                                       */
+                         /* 2 = in coordinates in which the (symmetric) score matrix is diagonal, score = SUM_r    */
+                         /*     d_r c_r c_r^T: the image holds t_r = c_r . p, both operands are read from it, d    */
+                         /*     rides on the per-index weights.  The speed of two images (46.2 vs 45.6 ms).  The   */
+                         /*     squares differ in sign: sums are exact for called genotypes (c, d dyadic for the   */
+                         /*     reference's matrices) and otherwise carry an ABSOLUTE error of <= 4e-17 per site   */
+                         /*     (1e-9 relative wherever a pair's mean per-site term is above 4e-8; seven digits    */
+                         /*     below the last one printed).  NGD_E_INVALID for an asymmetric score matrix.         */
+                         /* 1 = p resident, q formed for a range of sites at a time before the launch that reads   */
+                         /*     it: the arithmetic of two images (sums equal to rounding, per-block partial sums    */
+                         /*     bit for bit), any score matrix, a fifth more time (55.6 ms)                         */
+  uint32_t second_image_mib; /* single_image = 1: MiB of q kept resident all the same, from the first site on      */
+                         /* (what the device has to spare): only the rest is formed range by range, and the extra */
+                         /* time shrinks in proportion                                                             */
 } ngd_config;
 
 /* Per-run device timings (HIP events on the engine's stream). */

@@ -45,7 +45,9 @@ struct ngd_engine {
   // resident data set
   double *PA = nullptr, *QB = nullptr, *PI = nullptr;
   // ngd_config.single_image (MFMA kernel): QB is not resident; a launch forms it for a range of k-groups at a time
-  bool single_image = false;
+  bool single_image = false;    // (ngd_config.single_image = 1: q is formed range by range)
+  bool congruent = false;       // ngd_config.single_image = 2: the image holds t (sc.c, sc.d), read for both operands
+  double *d_wD = nullptr;       // ... and these are the weights of a plain pass: sc.d[k % 3] per contraction index
   double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
   uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
@@ -149,6 +151,61 @@ static int ensure_cap(ngd_engine *e, T **p, uint64_t *cap, uint64_t need) {
   return NGD_OK;
 }
 
+// ngd_config.single_image = 2: the symmetric score matrix as a sum of three weighted squares, S = SUM_r d[r] c_r c_r^T
+// (Lagrange's reduction; c row-major: c[3 r + g]).  With t_r = c_r . p per site, p1^T S p2 = SUM_r d[r] t_r(p1) t_r(p2):
+// ONE image (t) serves both operands of the MFMA kernel and d rides on the per-index weights.  Every step divides by a
+// diagonal entry or by twice an off-diagonal one only: for the reference's two matrices (parse_args.cpp:25-27, :134-137:
+// entries 0, 0.5, 1) c and d are small dyadic numbers, t is exact for called genotypes and so are the sums.
+// Returns false if S is not symmetric or the reconstruction does not give S back to 1e-15.
+static bool congruence(const double *S, double *c, double *d) {
+  double A[3][3];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      if (S[3 * a + b] != S[3 * b + a] || !std::isfinite(S[3 * a + b])) return false;
+      A[a][b] = S[3 * a + b];
+    }
+  int n = 0;
+  for (int r = 0; r < 9; r++) c[r] = 0;
+  for (int r = 0; r < 3; r++) d[r] = 0;
+  auto deflate = [&](const double *row, double w) {  // A -= w row row^T, the square joins the list
+    for (int g = 0; g < 3; g++) c[3 * n + g] = row[g];
+    d[n++] = w;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) A[a][b] -= w * row[a] * row[b];
+  };
+  while (n < 3) {
+    int pa = -1;
+    for (int a = 0; a < 3; a++)
+      if (A[a][a] != 0 && (pa < 0 || std::fabs(A[a][a]) > std::fabs(A[pa][pa]))) pa = a;
+    if (pa >= 0) {  // a square on the diagonal: A[a][a] (x_a + SUM_b A[a][b] / A[a][a] x_b)^2
+      const double piv = A[pa][pa];
+      double row[3];
+      for (int g = 0; g < 3; g++) row[g] = A[pa][g] / piv;
+      deflate(row, piv);
+      continue;
+    }
+    int qa = -1, qb = -1;
+    for (int a = 0; a < 3; a++)
+      for (int b = a + 1; b < 3; b++)
+        if (A[a][b] != 0 && (qa < 0 || std::fabs(A[a][b]) > std::fabs(A[qa][qb]))) { qa = a; qb = b; }
+    if (qa < 0) break;  // nothing left: rank below 3, the remaining weights stay 0
+    if (n > 1) return false;  // (two squares needed)
+    // no square, a mixed term: with r_a, r_b the two rows, 2 / beta r_a r_b = 1 / (2 beta) ((r_a + r_b)^2 - (r_a - r_b)^2)
+    const double beta = A[qa][qb];
+    double plus[3], minus[3];
+    for (int g = 0; g < 3; g++) { plus[g] = A[qa][g] + A[qb][g]; minus[g] = A[qa][g] - A[qb][g]; }
+    deflate(plus, 1.0 / (2 * beta));
+    deflate(minus, -1.0 / (2 * beta));
+  }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double r = 0;
+      for (int k = 0; k < 3; k++) r += d[k] * c[3 * k + a] * c[3 * k + b];
+      if (std::fabs(r - S[3 * a + b]) > 1e-15 * (1 + std::fabs(S[3 * a + b]))) return false;
+    }
+  return true;
+}
+
 // Single-image engines: k-groups of the second operand image formed at a time by default (4 GB of them)
 static uint64_t single_image_span(const ngd_geom &g) {
   return std::max<uint64_t>(1, std::min<uint64_t>(g.n_kg, (4ull << 30) / ((uint64_t)g.n_ig * 64 * 8)));
@@ -198,7 +255,7 @@ void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
   if (e->st) hipStreamSynchronize(e->st);
-  void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_kgl, e->d_kgcnt,
+  void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
   for (void *p : ptrs)
@@ -225,9 +282,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // tile lists index groups of 16 individuals with 16 bits; what bounds n_ind in practice is device memory (two
   // n_pairs-long result arrays + one n_pad x n_pad plane per slice), checked below before any list is built
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
-  if (cfg->single_image > 1) return fail(NGD_E_INVALID, "ngd_create: single_image is 0 or 1");
-  if (cfg->second_image_mib && !cfg->single_image)
-    return fail(NGD_E_INVALID, "ngd_create: second_image_mib belongs to single_image engines");
+  if (cfg->single_image > 2) return fail(NGD_E_INVALID, "ngd_create: single_image is 0, 1 or 2");
+  if (cfg->second_image_mib && cfg->single_image != 1)
+    return fail(NGD_E_INVALID, "ngd_create: second_image_mib belongs to single_image = 1 engines");
   if (cfg->exact_shapes > 6)
     return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
                                "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup) or 6 (5 with operands "
@@ -483,12 +540,18 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     TRY(dev_alloc(e, &e->PI, g.n_ind * g.n_sites_pad * 3, true));
   } else {
     TRY(dev_alloc(e, &e->PA, frag_elems, true));
-    e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image;
+    e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image == 1;
+    if (kernel == NGD_KERNEL_MFMA && cfg->single_image == 2) {
+      if (!congruence(cfg->score, e->sc.c, e->sc.d))
+        return bail(fail(NGD_E_INVALID, "ngd_create: single_image = 2 needs a symmetric score matrix (single_image = 1 takes any)"));
+      e->congruent = true;
+      e->sc.congruent = 1;
+    }
     if (e->single_image) {  // ... and as much of the second image as the caller has memory to spare for
       e->qb_res_kg = std::min<uint64_t>(g.n_kg, ((uint64_t)cfg->second_image_mib << 20) / ((uint64_t)g.n_ig * 64 * 8));
       if (e->qb_res_kg == g.n_kg) { e->single_image = false; e->qb_res_kg = 0; }  // all of it: the two-image engine
     }
-    if (kernel == NGD_KERNEL_MFMA && !e->single_image) TRY(dev_alloc(e, &e->QB, frag_elems, true));
+    if (kernel == NGD_KERNEL_MFMA && !e->single_image && !e->congruent) TRY(dev_alloc(e, &e->QB, frag_elems, true));
     if (e->qb_res_kg) TRY(dev_alloc(e, &e->QB_res, (e->qb_res_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64, false));
   }
   if (cfg->pairwise_del) {
@@ -497,6 +560,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   }
   TRY(dev_alloc(e, &e->d_ws, g.n_sites_pad + 4 * NGD_KG_TAIL, true));
   if (kernel == NGD_KERNEL_MFMA) TRY(dev_alloc(e, &e->d_wk, 4 * (g.n_kg + NGD_KG_TAIL), true));
+  if (e->congruent) {
+    TRY(dev_alloc(e, &e->d_wD, 4 * (g.n_kg + NGD_KG_TAIL), false));
+    ngd_launch_index_weights(e->st, 4 * (g.n_kg + NGD_KG_TAIL), e->sc.d, e->d_wD);
+  }
   TRY(dev_alloc(e, &e->d_sum, n_pairs, true));
   TRY(dev_alloc(e, &e->d_cnt, n_pairs, true));
 
@@ -742,7 +809,9 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
   switch (e->kernel) {
     case NGD_KERNEL_MFMA:
       if (!e->single_image) {
-        ngd_launch_accum_mfma(e->st, g, e->PA, e->QB, k_per_slice ? e->d_wslice : (w ? e->d_wk : nullptr),
+        // (single_image = 2: both operands from the one image, the congruence's diagonal on the weights -- of a plain pass too)
+        ngd_launch_accum_mfma(e->st, g, e->PA, e->congruent ? e->PA : e->QB,
+                              k_per_slice ? e->d_wslice : (w ? e->d_wk : (e->congruent ? e->d_wD : nullptr)),
                                 (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
                                 kg_lim, k_per_slice, w_stride, slab, e->d_clk);
       } else {
@@ -878,7 +947,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
       e->cap_blocks = n_blocks;
     }
     HIPCHK(hipMemcpyAsync(e->d_mult, mult, n_blocks * 4, hipMemcpyHostToDevice, e->st));
-    ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws, e->d_wk);
+    ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_mult, e->d_ws, e->d_wk, e->congruent ? e->sc.d : nullptr);
     if (list_pass) {  // the k-groups this replicate visits at all (about 1/e of the sites are not drawn)
       const uint32_t nb = ngd_kg_count_blocks(g.n_kg);
       if (!e->d_kgl) {
@@ -1019,7 +1088,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
       const uint32_t w_stride = (uint32_t)((3 * block_size + 3) / 4 + 1 + NGD_KG_TAIL);
       rc = ensure_cap(e, &e->d_wslice, &e->cap_wslice, (uint64_t)e->boot_nks * w_stride * 4);
       if (rc) return rc;
-      ngd_launch_slice_weights(e->st, e->boot_nks, w_stride, 3 * block_size, 3 * n_eff, e->d_wslice);
+      ngd_launch_slice_weights(e->st, e->boot_nks, w_stride, 3 * block_size, 3 * n_eff, e->d_wslice, e->congruent ? e->sc.d : nullptr);
       rc = launch_accumulate(e, nullptr, nullptr, n_eff, e->boot_nks, 0, (3 * n_eff + 3) / 4, e->slab_boot, 3 * block_size,
                              w_stride);
     } else

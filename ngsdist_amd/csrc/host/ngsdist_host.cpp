@@ -24,8 +24,9 @@
 //    genotypes, <= 1e-12 relative otherwise), --device D (first device), --same_device (every range on --device: a
 //    rehearsal on one GPU), --max_device_bytes B (device budget; a data set above it goes through in several ranges
 //    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful, --single_image (--indep_geno on the MFMA
-//    kernel: ngd_config.single_image -- half the device memory per site, so twice the sites per range, up to a quarter
-//    slower: what the device budget leaves is given to the first part of the second image, ngd_config.second_image_mib),
+//    kernel: ngd_config.single_image = 2 -- ONE operand image in coordinates in which the score matrix is diagonal: half
+//    the device memory per site, so twice the sites per range, the same speed; called genotypes print the same bytes,
+//    likelihoods agree to 4e-17 per site),
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -960,9 +961,6 @@ int main(int argc, char **argv) {
   int n_dev = ngd_device_count();
   if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
   if (p.device + (p.same_device ? 1 : p.n_gpus) > n_dev) die(__FUNCTION__, "not enough HIP devices for --device/--n_gpus");
-  // (--single_image: what the device budget leaves after the one image is given to the first part of the second,
-  // ngd_config.second_image_mib -- half of it when bootstrap partial sums will want room too; set by the plan below)
-  uint64_t plan_budget = 0, plan_fixed = 0, plan_per_site = 0, plan_n_pad = 0;
   auto make_engine = [&](Engine &eng, uint64_t n_sites_part, int dev_index) {
     ngd_config cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -973,13 +971,7 @@ int main(int argc, char **argv) {
     cfg.indep_geno = p.indep_geno;
     cfg.device = p.same_device ? p.device : p.device + dev_index;
     cfg.kernel = p.kernel;
-    cfg.single_image = p.single_image ? 1 : 0;  // (means something to the MFMA kernel only)
-    if (p.single_image && plan_budget) {
-      const uint64_t need = plan_fixed + plan_per_site * n_sites_part;
-      uint64_t spare = plan_budget > need ? plan_budget - need : 0;
-      if (p.n_boot_rep) spare /= 2;
-      cfg.second_image_mib = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(spare, 24 * plan_n_pad * n_sites_part) >> 20, 0xffffffffu);
-    }
+    cfg.single_image = p.single_image ? 2 : 0;  // (the MFMA kernel on one operand image; nothing to the other kernels)
     int rc = ngd_create(&cfg, &eng.h);
     if (rc) die_engine("ngd_create", rc);
   };
@@ -995,15 +987,12 @@ int main(int argc, char **argv) {
   const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path && !p.single_image ? 48 : 24) * n_pad) +
                             (p.pairwise_del ? p.n_ind / 8 + 1 : 0) + 40;
   const uint64_t n_t = n_pad / 128, n_slabs = std::max<uint64_t>(8, std::min<uint64_t>(256, 8192 / (n_t * (n_t + 1) / 2)));
-  const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20) +
-                         (mfma_path && p.single_image ? std::min<uint64_t>(4ull << 30, 24 * n_pad * p.n_sites) + (64ull << 20)
-                                                      : 0);  // (the range of the second image formed at a time)
+  const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);
   uint64_t dev_free = 0, dev_total = 0;
   if (ngd_device_memory(p.device, &dev_free, &dev_total)) die_engine("ngd_device_memory", -1);
   if (p.same_device) dev_free /= (uint64_t)p.n_gpus;  // the rehearsal's ranges share one device
   const uint64_t budget = p.max_device_bytes ? p.max_device_bytes : dev_free / 100 * 85;
   const bool in_parts = p.n_gpus > 1 || fixed + per_site * p.n_sites > budget;
-  plan_budget = budget; plan_fixed = fixed; plan_per_site = per_site; plan_n_pad = n_pad;
 
   if (p.verbose >= 2) fprintf(stderr, "==> Setting seed for random number generator\n");
   uint32_t rng[3];

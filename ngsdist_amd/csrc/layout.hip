@@ -7,6 +7,11 @@
 
 namespace {
 
+struct ngd_d3 {
+  double v[3];
+};
+inline ngd_d3 d3_of(const double *d3) { return d3 ? ngd_d3{{d3[0], d3[1], d3[2]}} : ngd_d3{{1.0, 1.0, 1.0}}; }
+
 // One (individual, site): write every image that is allocated.
 __device__ __forceinline__ void emit(const ngd_geom &g, const ngd_score &sc, int pairwise_del,
                                      uint64_t s, uint32_t i, double p0, double p1, double p2,
@@ -19,7 +24,14 @@ __device__ __forceinline__ void emit(const ngd_geom &g, const ngd_score &sc, int
   if (mask && !miss) atomicOr(&mask[(uint64_t)i * g.n_words + (s >> 6)], 1ull << (s & 63));
   if (pairwise_del && miss) { p0 = 0; p1 = 0; p2 = 0; }  // a skipped site contributes nothing
   uint64_t k = 3 * s;
-  if (PA) {
+  if (PA && sc.congruent) {  // t_r = c_r . p (products and sums rounded one by one; exact for called genotypes)
+    for (int r = 0; r < 3; r++) {
+      double t = sc.c[3 * r] * p0;
+      t = t + sc.c[3 * r + 1] * p1;
+      t = t + sc.c[3 * r + 2] * p2;
+      PA[ngd_frag_off(k + r, i, g.n_ig)] = t;
+    }
+  } else if (PA) {
     PA[ngd_frag_off(k, i, g.n_ig)] = p0;
     PA[ngd_frag_off(k + 1, i, g.n_ig)] = p1;
     PA[ngd_frag_off(k + 2, i, g.n_ig)] = p2;
@@ -181,16 +193,21 @@ __global__ void k_synth(ngd_geom g, uint64_t seed, double miss_frac, uint64_t si
 // same thing per contraction index k = 3 s + g as a double, wk[k], so that its operand pipeline fetches the
 // weight of a k-group like any other operand (no integer division, no conversion in the hot loop)
 __global__ void k_expand(const uint32_t *__restrict__ mult, uint64_t n_eff, uint64_t block_size,
-                         uint64_t n_sites, uint32_t *ws, double *wk) {
+                         uint64_t n_sites, uint32_t *ws, double *wk, ngd_d3 d3) {
   uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_sites) return;
   const uint32_t m = s < n_eff ? mult[s / block_size] : 0u;
   ws[s] = m;
-  if (wk) {
-    wk[3 * s] = (double)m;
-    wk[3 * s + 1] = (double)m;
-    wk[3 * s + 2] = (double)m;
+  if (wk) {  // (d3: 1, 1, 1 -- or the congruence's diagonal, single_image = 2)
+    wk[3 * s] = (double)m * d3.v[0];
+    wk[3 * s + 1] = (double)m * d3.v[1];
+    wk[3 * s + 2] = (double)m * d3.v[2];
   }
+}
+
+__global__ void k_index_weights(uint64_t n_k, ngd_d3 d3, double *W) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_k) W[k] = d3.v[k % 3];
 }
 
 // W[s][RB] for the EM batch kernel: replicate r's multiplicity of site s (mult is [n_rep][n_blocks]); rows
@@ -214,13 +231,14 @@ __global__ void k_expand_batch(const uint32_t *__restrict__ mult, uint32_t n_rep
 }
 
 // 0/1 weights per slice for bootstrap blocks that are not whole k-groups (accum_mfma.hip, k_per_slice)
-__global__ void k_slice_weights(uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total, double *W) {
+__global__ void k_slice_weights(uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total, double *W,
+                                ngd_d3 d3) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (uint64_t)n_slices * stride * 4) return;
   const uint64_t slice = t / ((uint64_t)stride * 4), r = t % ((uint64_t)stride * 4);
   const uint64_t k = (((slice * k_per_slice) >> 2) << 2) + r;
   const uint64_t lo = slice * k_per_slice, hi = lo + k_per_slice < k_total ? lo + k_per_slice : k_total;
-  W[t] = (k >= lo && k < hi) ? 1.0 : 0.0;
+  W[t] = (k >= lo && k < hi) ? d3.v[k % 3] : 0.0;
 }
 
 // bit-planes of the per-site multiplicity, for weighted valid-site counts
@@ -374,9 +392,13 @@ void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double m
 }
 
 void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
-                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk) {
+                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk, const double *d3) {
   hipLaunchKernelGGL(k_expand, dim3((unsigned)((n_sites + 255) / 256)), dim3(256), 0, st, d_mult,
-                     n_blocks * block_size, block_size, n_sites, d_ws, d_wk);
+                     n_blocks * block_size, block_size, n_sites, d_ws, d_wk, d3_of(d3));
+}
+
+void ngd_launch_index_weights(hipStream_t st, uint64_t n_k, const double *d3, double *d_W) {
+  hipLaunchKernelGGL(k_index_weights, dim3((unsigned)((n_k + 255) / 256)), dim3(256), 0, st, n_k, d3_of(d3), d_W);
 }
 
 void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n_rep, uint32_t rb, int lead_full,
@@ -387,11 +409,11 @@ void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n
 }
 
 void ngd_launch_slice_weights(hipStream_t st, uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total,
-                              double *d_W) {
+                              double *d_W, const double *d3) {
   const uint64_t n = (uint64_t)n_slices * stride * 4;
   if (!n) return;
   hipLaunchKernelGGL(k_slice_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_slices, stride, k_per_slice,
-                     k_total, d_W);
+                     k_total, d_W, d3_of(d3));
 }
 
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,

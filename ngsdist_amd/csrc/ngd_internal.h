@@ -15,6 +15,11 @@ typedef double ngd_d4 __attribute__((ext_vector_type(4)));
 
 struct ngd_score {
   double v[9];
+  // single_image = 2 (engine.hip congruence()): score = SUM_r d[r] c_r c_r^T.  The ONE operand image then holds
+  // t_r = c_r . p per site instead of p, both operands of the MFMA kernel are read from it, and d[r] rides on the
+  // per-index weights.  congruent = 0: the image holds p.
+  double c[9], d[3];
+  int congruent;
 };
 
 // Geometry of the resident data set.
@@ -82,7 +87,7 @@ void ngd_launch_synth(hipStream_t st, const ngd_geom &g, uint64_t seed, double m
                       const ngd_score &score, int pairwise_del, double *PA, double *QB, double *PI,
                       unsigned long long *mask);
 void ngd_launch_weights(hipStream_t st, uint64_t n_blocks, uint64_t block_size, uint64_t n_sites,
-                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk);
+                        const uint32_t *d_mult, uint32_t *d_ws, double *d_wk, const double *d3 = nullptr);
 // list of the k-groups with a non-zero bootstrap weight (ascending), NGD_KG_LIST_PAD entries of padding;
 // d_counts: ngd_kg_count_blocks(n_kg) + 1 words of scratch, the last one receives the list length
 uint32_t ngd_kg_count_blocks(uint64_t n_kg);
@@ -94,7 +99,9 @@ void ngd_launch_weights_batch(hipStream_t st, const uint32_t *d_mult, uint32_t n
 // W[slice][j][c] = 1 if contraction index 4 (kg0(slice) + j) + c lies in [slice k_per_slice, (slice+1) k_per_slice)
 // and below k_total, else 0; kg0(slice) = slice * k_per_slice / 4; j < stride
 void ngd_launch_slice_weights(hipStream_t st, uint32_t n_slices, uint32_t stride, uint64_t k_per_slice, uint64_t k_total,
-                              double *d_W);
+                              double *d_W, const double *d3 = nullptr /* weight of index k inside a slice: d3[k % 3], not 1 */);
+// single_image = 2: the weights of a plain pass, d3[k % 3] for every contraction index of the images (+ tail)
+void ngd_launch_index_weights(hipStream_t st, uint64_t n_k, const double *d3, double *d_W);
 void ngd_launch_planes(hipStream_t st, const uint32_t *d_ws, uint64_t n_sites, uint32_t n_words,
                        uint32_t n_planes, unsigned long long *d_planes);
 

@@ -66,7 +66,8 @@ class Engine:
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
         # launch geometry, 0 = the engine's defaults (ngd_config)
         cfg.variant, cfg.n_slices, cfg.wg_target, cfg.exact_shapes = int(variant), int(n_slices), int(wg_target), int(exact_shapes)
-        cfg.single_image = int(bool(single_image))  # MFMA kernel: one resident operand image, the other formed per launch
+        # MFMA kernel: one resident operand image -- 1 / True: the other formed per launch, 2: congruent coordinates
+        cfg.single_image = int(single_image)
         cfg.second_image_mib = int(second_image_bytes) >> 20  # ... except this much of it, kept resident all the same
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
         self.n_pairs = n_pairs(self.n_ind)

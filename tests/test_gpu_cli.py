@@ -298,17 +298,14 @@ def test_multi_gpu_site_ranges_on_one_device(tmp_path):
 
 
 def test_single_image_flag_prints_the_same_bytes(tmp_path):
-    """--single_image (ngd_config.single_image: p resident, q = score . p formed a range of sites at a time): called
-    genotypes print the same bytes (bootstrap, --pairwise_del, site ranges on several engines included); GL data
-    equal to 1e-9; on the EM path the flag changes nothing"""
+    """--single_image (ngd_config.single_image = 2: one operand image in coordinates in which the score matrix is
+    diagonal): called genotypes print the same bytes (bootstrap, --pairwise_del, --avg_nuc_dist, site ranges on several
+    engines included); GL data equal to 1e-9; on the EM path the flag changes nothing"""
     path, lpath, labels = _testA_like(tmp_path)
-    base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345]
-    # (with memory to spare the host keeps the whole second image after all -- ngd_config.second_image_mib; the device
-    # budgets below leave room for none of it / for about half of it at this size)
-    for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--n_boot_rep", 2, "--n_gpus", 2, "--same_device"]):
-        two = cli(tmp_path, *base, *extra, name="two.dist")
-        for budget in ([], ["--max_device_bytes", 700_000_000], ["--max_device_bytes", 715_000_000]):
-            assert cli(tmp_path, *base, *extra, "--single_image", *budget, name="single.dist") == two
+    base = ["--geno", path, "--n_ind", 24, "--n_sites", 10000, "--labels", lpath, "--seed", 12345, "--indep_geno"]
+    for extra in ([], ["--n_boot_rep", 3, "--boot_block_size", 10, "--pairwise_del"], ["--avg_nuc_dist", "--evol_model", 0],
+                  ["--n_boot_rep", 2, "--n_gpus", 2, "--same_device"]):
+        assert cli(tmp_path, *base, *extra, "--single_image", name="single.dist") == cli(tmp_path, *base, *extra, name="two.dist")
     n_ind, n_sites = 300, 2000
     raw = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.1).transpose(1, 0, 2).copy()
     gl = tmp_path / "g.bin"

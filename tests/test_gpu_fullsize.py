@@ -93,8 +93,9 @@ def test_cfg3_streaming_kernel_agrees_on_every_pair(cfg3_mfma):
 
 
 def test_cfg3_single_image_engine(cfg3_mfma):
-    """ngd_config.single_image at full size: 31 GB resident instead of 51 (p only; q = score . p formed a range of sites
-    at a time beside the kernel), the whole pass equal to rounding, per-block partial sums bit for bit"""
+    """ngd_config.single_image at full size.  1: 30 GB resident instead of 51 (p only; q = score . p formed a range of
+    sites at a time), the whole pass equal to rounding, per-block partial sums bit for bit.  2: 27 GB (one image in
+    coordinates in which the score matrix is diagonal), everything equal to rounding."""
     full, cnt = cfg3_mfma.run()
     perm = np.random.default_rng(0).permutation(np.arange(1000, dtype=np.uint64))
     cfg3_mfma.set_option("boot_partials", 2)
@@ -111,6 +112,19 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         e.set_option("boot_partials", 2)  # (per-block partial sums from the first replicate on, as the fixture's engine has them by now)
         sp, _ = e.run(perm, 1000)
         assert np.array_equal(sp, s_perm)
+        e.set_option("boot_partials", 0)
+        sw, _ = e.run(perm, 1000)
+        assert rel(sw, s_perm) < 1e-12
+    # single_image = 2, the one image in congruent coordinates: 27 GB, sums to 1e-12, partial sums too
+    with N().Engine(1000, 1_000_000, kernel="mfma", single_image=2) as e:
+        e.synth_fill(3)
+        assert e.device_bytes() < 28e9
+        s, c = e.run()
+        assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
+        assert np.array_equal(e.run()[0], s)
+        e.set_option("boot_partials", 2)
+        sp, _ = e.run(perm, 1000)
+        assert rel(sp, s_perm) < 1e-12
         e.set_option("boot_partials", 0)
         sw, _ = e.run(perm, 1000)
         assert rel(sw, s_perm) < 1e-12

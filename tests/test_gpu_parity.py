@@ -533,6 +533,89 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes, resident):
     assert np.array_equal(one[3][1], cb) and rel_err(one[3][0], sb) < RTOL
 
 
+@pytest.mark.parametrize("n_ind,form", [(64, 0), (200, 0), (200, 2), (600, 0), (130, 1), (33, 4)])
+@pytest.mark.parametrize("avg_nuc_dist", [False, True])
+def test_mfma_congruent_single_image_engine(n_ind, form, avg_nuc_dist):
+    """ngd_config.single_image = 2 (engine.hip congruence()): the score matrix as a sum of three weighted squares,
+    score = SUM_r d_r c_r c_r^T, so ONE image t_r = c_r . p serves both operands of the MFMA kernel and d rides on the
+    per-index weights (ngsDist.cpp:351-353 regrouped once more).  Both of the reference's matrices
+    (parse_args.cpp:25-27, :134-137): every pair against the oracle -- plain pass, a weighted pass, per-block partial
+    sums with blocks of 8 sites and of 6 (masked slices), --pairwise_del; called genotypes bit for bit with the two-image
+    engine (c, d dyadic: every product and sum exact); half the device memory."""
+    n_sites = 3000
+    score = O.score_matrix(avg_nuc_dist)
+    p = O.synth_indmajor(91 + n_ind, n_ind, n_sites, miss_frac=0.1)
+    rng = np.random.default_rng(n_ind)
+    pc = np.zeros((n_ind, n_sites, 3))
+    np.put_along_axis(pc, rng.integers(0, 3, size=(n_ind, n_sites))[..., None], 1.0, axis=2)
+    out = []
+    for single in (0, 2):
+        with N().Engine(n_ind, n_sites, score=score, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single) as e:
+            e.upload_ind_major(p).commit()
+            r = [e.run()]
+            for B, partials in ((8, 2), (6, 2), (7, 0)):
+                m = N().Taus(B + n_ind).block_map(n_sites // B)
+                e.set_option("boot_partials", partials)
+                r.append(e.run(m, B))
+            nbytes = e.device_bytes()
+        with N().Engine(n_ind, n_sites, score=score, kernel="mfma", exact_shapes=form, single_image=single) as e:
+            e.upload_ind_major(pc).commit()
+            r.append(e.run())
+            for B, partials in ((8, 2), (7, 0)):
+                e.set_option("boot_partials", partials)
+                r.append(e.run(N().Taus(B + n_ind).block_map(n_sites // B), B))
+        out.append((r, nbytes))
+    (two, bytes_two), (one, bytes_one) = out
+    assert bytes_one < bytes_two
+    for k in (4, 5, 6):  # called genotypes
+        assert np.array_equal(two[k][0], one[k][0]) and np.array_equal(two[k][1], one[k][1]), k
+    so, co = O.all_pairs(p, score=score, pairwise_del=True, n_threads=8)
+    assert np.array_equal(one[0][1], co) and rel_err(one[0][0], so) < RTOL
+    for k, B in ((1, 8), (2, 6), (3, 7)):
+        m = N().Taus(B + n_ind).block_map(n_sites // B)
+        sb, cb = O.all_pairs(p, score=score, pairwise_del=True, site_src=O.boot_site_src(m, B), n_sites=n_sites // B * B, n_threads=8)
+        assert np.array_equal(one[k][1], cb) and rel_err(one[k][0], sb) < RTOL, k
+
+
+def test_congruent_single_image_accuracy_on_nearly_identical_individuals():
+    """what single_image = 2 gives up: the three squares carry different signs, so a pair's sum is a difference of terms
+    of order 1 per site and its ABSOLUTE error is that of those terms -- a few 1e-17 per site (here, on copies of one
+    individual, of one sign: it adds up linearly) -- relative to the sum only as long as the per-site terms are not tiny.
+    Copies of one individual with likelihoods confident to 1e-9: per-site terms of 4e-9, sums of 2e-5.  The two-image
+    engine holds 1e-9 relative there (all terms positive); the one-image engine holds 4e-17 per site (measured 1.7e-17),
+    i.e. 4e-9 of these sums -- and 1e-9 relative wherever a pair's mean per-site term is above 4e-8 (ordinary distances,
+    test above: 1e-13).  In the printed matrix (%.10f of sum / n_sites) 4e-17 per site is seven digits below the last."""
+    n_ind, n_sites = 32, 5000
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 3, size=n_sites)
+    eps = 1e-9 * (1 + rng.random((n_ind, n_sites, 3)))
+    p = eps.copy()
+    p[:, np.arange(n_sites), g] = 0
+    p[:, np.arange(n_sites), g] = 1 - p.sum(axis=2)
+    so, co = O.all_pairs(p, n_threads=8)
+    assert so.max() < 1e-4
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+        s2, _ = e.upload_ind_major(p).commit().run()
+    with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
+        s1, c1 = e.upload_ind_major(p).commit().run()
+    assert np.array_equal(c1, co) and rel_err(s2, so) < RTOL
+    assert np.max(np.abs(s1 - so)) < 4e-17 * n_sites
+    assert np.array_equal(np.round(s1 / n_sites, 10), np.round(so / n_sites, 10))
+
+
+def test_congruent_single_image_needs_a_symmetric_score_matrix():
+    """single_image = 2 rests on a congruence of the score matrix; an asymmetric one is refused (single_image = 1 takes it)"""
+    score = O.score_matrix(False).copy()
+    score[1] = 0.25  # score[0][1] != score[1][0]
+    with pytest.raises(N().NgdError):
+        N().Engine(40, 512, score=score, kernel="mfma", single_image=2)
+    p = O.synth_indmajor(8, 40, 512)
+    so, co = O.all_pairs(p, score=score, n_threads=8)
+    with N().Engine(40, 512, score=score, kernel="mfma", single_image=1) as e:
+        s, c = e.upload_ind_major(p).commit().run()
+    assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+
+
 def test_single_image_is_an_mfma_engine_option():
     """other kernels hold one image anyway: the flag is accepted and changes nothing; the option that sizes the
     scratch is refused without it, second_image_mib too; with room for the whole second image the engine is the

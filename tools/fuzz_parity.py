@@ -39,8 +39,9 @@ for case in range(first, first + n_cases):
     single = kernel == "mfma" and bool(rng_si.integers(0, 2))  # ngd_config.single_image; the scratch: 4 GB or the smallest ranges
     single_bytes = int(rng_si.choice([0, 1, 1 << 20])) if single else 0
     if single:
-        geom["single_image"] = True
-        geom["second_image_bytes"] = int(rng_si.choice([0, 0, 1 << 20, 2 << 20]))  # part of the second image kept resident
+        geom["single_image"] = int(rng_si.integers(1, 3))  # 1: the second image formed in ranges; 2: congruent coordinates
+        if geom["single_image"] == 1:
+            geom["second_image_bytes"] = int(rng_si.choice([0, 0, 1 << 20, 2 << 20]))  # part of the second image kept resident
     score = O.score_matrix(bool(rng.integers(0, 2)))
     model = int(rng.integers(0, 3))
     p = O.synth_indmajor(1000 + case, n_ind, n_sites, miss_frac=miss)
