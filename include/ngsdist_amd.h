@@ -313,6 +313,10 @@ uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2); /* i1 < i2 */
 uint32_t ngd_shard_of_pair(uint64_t n_ind, uint64_t i1, uint64_t i2, uint32_t shard_world);
 /* the same for every pair, in pair order: owner[ngd_pair_index(n_ind, i1, i2)] (n_pairs entries) */
 void ngd_shard_map(uint64_t n_ind, uint32_t shard_world, int32_t *owner);
+/* ngd_config.single_image = 2: the symmetric score matrix as a sum of three weighted squares,
+ * score = SUM_r d[r] c_r c_r^T with c row-major (c[3 r + g]) -- Lagrange's reduction, dyadic c and d for the reference's
+ * two matrices (parse_args.cpp:25-27, :134-137).  NGD_E_INVALID for an asymmetric matrix.  Pure host arithmetic. */
+int ngd_score_congruence(const double score[9], double c[9], double d[3]);
 /* free / total memory of a device (device < 0: the current one): lets a host decide whether a data set fits one
  * engine or has to go through it a range of sites at a time (site sharding in time instead of across GPUs) */
 int ngd_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);

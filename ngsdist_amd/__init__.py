@@ -6,7 +6,7 @@ the library; the first Engine()/finish()/Taus() does, and fails loudly if the
 HIP engine was not built.
 """
 from .engine import (DEFAULT_SCORE, KERNELS, Engine, NgdError, Taus, device_count, finish, format_matrix, n_pairs,
-                     score_matrix)
+                     score_congruence, score_matrix)
 
 __all__ = ["Engine", "NgdError", "Taus", "finish", "format_matrix", "device_count", "n_pairs", "score_matrix",
-           "DEFAULT_SCORE", "KERNELS"]
+           "score_congruence", "DEFAULT_SCORE", "KERNELS"]

@@ -57,6 +57,7 @@ EXPORTS = [
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
     "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair", "ngd_shard_map",
+    "ngd_score_congruence",
 ]
 
 _lib = None
@@ -134,6 +135,8 @@ def load():
     L.ngd_shard_of_pair.restype = C.c_uint32
     L.ngd_shard_map.argtypes = [u64, C.c_uint32, C.POINTER(C.c_int32)]
     L.ngd_shard_map.restype = None
+    L.ngd_score_congruence.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ngd_score_congruence.restype = C.c_int
     L.ngd_device_bytes.argtypes = [vp]
     L.ngd_device_bytes.restype = u64
     _lib = L

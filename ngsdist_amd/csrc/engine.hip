@@ -151,61 +151,6 @@ static int ensure_cap(ngd_engine *e, T **p, uint64_t *cap, uint64_t need) {
   return NGD_OK;
 }
 
-// ngd_config.single_image = 2: the symmetric score matrix as a sum of three weighted squares, S = SUM_r d[r] c_r c_r^T
-// (Lagrange's reduction; c row-major: c[3 r + g]).  With t_r = c_r . p per site, p1^T S p2 = SUM_r d[r] t_r(p1) t_r(p2):
-// ONE image (t) serves both operands of the MFMA kernel and d rides on the per-index weights.  Every step divides by a
-// diagonal entry or by twice an off-diagonal one only: for the reference's two matrices (parse_args.cpp:25-27, :134-137:
-// entries 0, 0.5, 1) c and d are small dyadic numbers, t is exact for called genotypes and so are the sums.
-// Returns false if S is not symmetric or the reconstruction does not give S back to 1e-15.
-static bool congruence(const double *S, double *c, double *d) {
-  double A[3][3];
-  for (int a = 0; a < 3; a++)
-    for (int b = 0; b < 3; b++) {
-      if (S[3 * a + b] != S[3 * b + a] || !std::isfinite(S[3 * a + b])) return false;
-      A[a][b] = S[3 * a + b];
-    }
-  int n = 0;
-  for (int r = 0; r < 9; r++) c[r] = 0;
-  for (int r = 0; r < 3; r++) d[r] = 0;
-  auto deflate = [&](const double *row, double w) {  // A -= w row row^T, the square joins the list
-    for (int g = 0; g < 3; g++) c[3 * n + g] = row[g];
-    d[n++] = w;
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++) A[a][b] -= w * row[a] * row[b];
-  };
-  while (n < 3) {
-    int pa = -1;
-    for (int a = 0; a < 3; a++)
-      if (A[a][a] != 0 && (pa < 0 || std::fabs(A[a][a]) > std::fabs(A[pa][pa]))) pa = a;
-    if (pa >= 0) {  // a square on the diagonal: A[a][a] (x_a + SUM_b A[a][b] / A[a][a] x_b)^2
-      const double piv = A[pa][pa];
-      double row[3];
-      for (int g = 0; g < 3; g++) row[g] = A[pa][g] / piv;
-      deflate(row, piv);
-      continue;
-    }
-    int qa = -1, qb = -1;
-    for (int a = 0; a < 3; a++)
-      for (int b = a + 1; b < 3; b++)
-        if (A[a][b] != 0 && (qa < 0 || std::fabs(A[a][b]) > std::fabs(A[qa][qb]))) { qa = a; qb = b; }
-    if (qa < 0) break;  // nothing left: rank below 3, the remaining weights stay 0
-    if (n > 1) return false;  // (two squares needed)
-    // no square, a mixed term: with r_a, r_b the two rows, 2 / beta r_a r_b = 1 / (2 beta) ((r_a + r_b)^2 - (r_a - r_b)^2)
-    const double beta = A[qa][qb];
-    double plus[3], minus[3];
-    for (int g = 0; g < 3; g++) { plus[g] = A[qa][g] + A[qb][g]; minus[g] = A[qa][g] - A[qb][g]; }
-    deflate(plus, 1.0 / (2 * beta));
-    deflate(minus, -1.0 / (2 * beta));
-  }
-  for (int a = 0; a < 3; a++)
-    for (int b = 0; b < 3; b++) {
-      double r = 0;
-      for (int k = 0; k < 3; k++) r += d[k] * c[3 * k + a] * c[3 * k + b];
-      if (std::fabs(r - S[3 * a + b]) > 1e-15 * (1 + std::fabs(S[3 * a + b]))) return false;
-    }
-  return true;
-}
-
 // Single-image engines: k-groups of the second operand image formed at a time by default (4 GB of them)
 static uint64_t single_image_span(const ngd_geom &g) {
   return std::max<uint64_t>(1, std::min<uint64_t>(g.n_kg, (4ull << 30) / ((uint64_t)g.n_ig * 64 * 8)));
@@ -542,7 +487,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     TRY(dev_alloc(e, &e->PA, frag_elems, true));
     e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image == 1;
     if (kernel == NGD_KERNEL_MFMA && cfg->single_image == 2) {
-      if (!congruence(cfg->score, e->sc.c, e->sc.d))
+      if (ngd_score_congruence(cfg->score, e->sc.c, e->sc.d) != NGD_OK)
         return bail(fail(NGD_E_INVALID, "ngd_create: single_image = 2 needs a symmetric score matrix (single_image = 1 takes any)"));
       e->congruent = true;
       e->sc.congruent = 1;

@@ -241,6 +241,73 @@ void ngd_shard_map(uint64_t n_ind, uint32_t shard_world, int32_t *owner) {
     for (uint64_t j = i + 1; j < n_ind; j++) owner[k++] = (int32_t)own[ngd_tile_id(n_t, i / 128, j / 128)];
 }
 
+// ngd_config.single_image = 2 (engine.hip): the symmetric score matrix as a sum of three weighted squares, S = SUM_r d[r] c_r c_r^T
+// (Lagrange's reduction; c row-major: c[3 r + g]).  With t_r = c_r . p per site, p1^T S p2 = SUM_r d[r] t_r(p1) t_r(p2):
+// ONE image (t) serves both operands of the MFMA kernel and d rides on the per-index weights.  Every step divides by a
+// diagonal entry or by twice an off-diagonal one only: for the reference's two matrices (parse_args.cpp:25-27, :134-137:
+// entries 0, 0.5, 1) c and d are small dyadic numbers, t is exact for called genotypes and so are the sums.
+// NGD_E_INVALID if S is not symmetric or the reconstruction does not give S back to 1e-13 of its largest entry.  Pure host arithmetic.
+int ngd_score_congruence(const double *S, double *c, double *d) {
+  double A[3][3];
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      if (S[3 * a + b] != S[3 * b + a] || !std::isfinite(S[3 * a + b])) return NGD_E_INVALID;
+      A[a][b] = S[3 * a + b];
+    }
+  int n = 0;
+  for (int r = 0; r < 9; r++) c[r] = 0;
+  for (int r = 0; r < 3; r++) d[r] = 0;
+  double scale = 0;
+  for (int k = 0; k < 9; k++) scale = std::max(scale, std::fabs(S[k]));
+  const double tiny = 1e-14 * scale;  // what an elimination in floating point leaves of an exact zero
+  auto deflate = [&](const double *row, double w) {  // A -= w row row^T, the square joins the list
+    for (int g = 0; g < 3; g++) c[3 * n + g] = row[g];
+    d[n++] = w;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        A[a][b] -= w * row[a] * row[b];
+        if (std::fabs(A[a][b]) <= tiny) A[a][b] = 0;
+      }
+  };
+  auto clear = [&](int a) {  // the eliminated variable's row and column are zero by construction
+    for (int g = 0; g < 3; g++) A[a][g] = A[g][a] = 0;
+  };
+  while (n < 3) {
+    int pa = -1;
+    for (int a = 0; a < 3; a++)
+      if (A[a][a] != 0 && (pa < 0 || std::fabs(A[a][a]) > std::fabs(A[pa][pa]))) pa = a;
+    if (pa >= 0) {  // a square on the diagonal: A[a][a] (x_a + SUM_b A[a][b] / A[a][a] x_b)^2
+      const double piv = A[pa][pa];
+      double row[3];
+      for (int g = 0; g < 3; g++) row[g] = A[pa][g] / piv;
+      deflate(row, piv);
+      clear(pa);
+      continue;
+    }
+    int qa = -1, qb = -1;
+    for (int a = 0; a < 3; a++)
+      for (int b = a + 1; b < 3; b++)
+        if (A[a][b] != 0 && (qa < 0 || std::fabs(A[a][b]) > std::fabs(A[qa][qb]))) { qa = a; qb = b; }
+    if (qa < 0) break;  // nothing left: rank below 3, the remaining weights stay 0
+    if (n > 1) return NGD_E_INVALID;  // (two squares needed)
+    // no square, a mixed term: with r_a, r_b the two rows, 2 / beta r_a r_b = 1 / (2 beta) ((r_a + r_b)^2 - (r_a - r_b)^2)
+    const double beta = A[qa][qb];
+    double plus[3], minus[3];
+    for (int g = 0; g < 3; g++) { plus[g] = A[qa][g] + A[qb][g]; minus[g] = A[qa][g] - A[qb][g]; }
+    deflate(plus, 1.0 / (2 * beta));
+    deflate(minus, -1.0 / (2 * beta));
+    clear(qa);
+    clear(qb);
+  }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double r = 0;
+      for (int k = 0; k < 3; k++) r += d[k] * c[3 * k + a] * c[3 * k + b];
+      if (std::fabs(r - S[3 * a + b]) > 1e-13 * scale) return NGD_E_INVALID;
+    }
+  return NGD_OK;
+}
+
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites,
                uint64_t evol_model, double *dist) {
   if (evol_model > 2) return NGD_E_MODEL;  // reference: error("... model not yet supported")

@@ -15,7 +15,7 @@ typedef double ngd_d4 __attribute__((ext_vector_type(4)));
 
 struct ngd_score {
   double v[9];
-  // single_image = 2 (engine.hip congruence()): score = SUM_r d[r] c_r c_r^T.  The ONE operand image then holds
+  // single_image = 2 (host_util.cpp ngd_score_congruence()): score = SUM_r d[r] c_r c_r^T.  The ONE operand image then holds
   // t_r = c_r . p per site instead of p, both operands of the MFMA kernel are read from it, and d[r] rides on the
   // per-index weights.  congruent = 0: the image holds p.
   double c[9], d[3];

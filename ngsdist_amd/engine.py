@@ -265,6 +265,17 @@ def finish(sum_, cnt, tot_sites=0, evol_model=1, out=None):
     return out
 
 
+def score_congruence(score):
+    """the symmetric score matrix as three weighted squares, score = SUM_r d[r] c[r] c[r]^T (ngd_score_congruence: what
+    ngd_config.single_image = 2 builds its one operand image from).  Returns (c [3][3], d [3])."""
+    L = _lib.load()
+    s = np.ascontiguousarray(score, dtype=np.float64).reshape(9)
+    c, d = np.zeros(9), np.zeros(3)
+    dp = C.POINTER(C.c_double)
+    _check(L.ngd_score_congruence(s.ctypes.data_as(dp), c.ctypes.data_as(dp), d.ctypes.data_as(dp)))
+    return c.reshape(3, 3), d
+
+
 def format_matrix(dist, labels, n_threads=0):
     """The print block of one matrix (ngsDist.cpp:282-287) as bytes, from ngd_finish()'s pair-ordered output."""
     L = _lib.load()

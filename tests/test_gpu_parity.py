@@ -536,7 +536,7 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes, resident):
 @pytest.mark.parametrize("n_ind,form", [(64, 0), (200, 0), (200, 2), (600, 0), (130, 1), (33, 4)])
 @pytest.mark.parametrize("avg_nuc_dist", [False, True])
 def test_mfma_congruent_single_image_engine(n_ind, form, avg_nuc_dist):
-    """ngd_config.single_image = 2 (engine.hip congruence()): the score matrix as a sum of three weighted squares,
+    """ngd_config.single_image = 2 (host_util.cpp ngd_score_congruence()): the score matrix as a sum of three weighted squares,
     score = SUM_r d_r c_r c_r^T, so ONE image t_r = c_r . p serves both operands of the MFMA kernel and d rides on the
     per-index weights (ngsDist.cpp:351-353 regrouped once more).  Both of the reference's matrices
     (parse_args.cpp:25-27, :134-137): every pair against the oracle -- plain pass, a weighted pass, per-block partial
