@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 2
+#define NGD_ABI_VERSION 3 /* 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
