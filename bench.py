@@ -719,16 +719,17 @@ def main():
     # measured on is the one this library was built from (sha256 recorded by tools/pmc_summary.py)
     try:
         import hashlib
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.workload, kernel))))
+        tname = "traffic_%s_%s.json" % (args.workload, "single_image%d" % args.single_image if args.single_image else kernel)
+        tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
         now = hashlib.sha256(open(os.path.join(ROOT, "ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
         if tj.get("kernel_source_sha16", {}).get(src) != now:
-            roof["traffic_stale"] = "profiles/traffic_%s_%s.json was measured on another version of %s" % (args.workload, kernel, src)
+            roof["traffic_stale"] = "profiles/%s was measured on another version of %s" % (tname, src)
         else:
             for kname, v in tj["per_launch"].items():
                 if "accum" in kname:
                     roof["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
-                    roof["traffic_source"] = "profiles/traffic_%s_%s.json (%s)" % (args.workload, kernel, tj["source"])
+                    roof["traffic_source"] = "profiles/%s (%s)" % (tname, tj["source"])
                     break
     except Exception:
         pass
