@@ -824,9 +824,11 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
             ngd_launch_accum_mfma(e->st, g, e->PA + lo * kstride, e->qb_chunk, wsel ? wsel + lo * 4 : nullptr, nullptr, e->d_jobs,
                                   e->n_wg, e->exact_shapes, e->wg_waves, n_ks, piece, hi - lo, 0, 0, slab, e->d_clk, 0,
                                   r > 0 || res > 0);
-          else
-            ngd_launch_accum_mfma(e->st, g, e->PA, e->qb_chunk - lo * kstride, wsel, nullptr, e->d_jobs, e->n_wg,
-                                  e->exact_shapes, e->wg_waves, n, per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, ks0);
+          else {  // (the kernel indexes the image by absolute k-group: an address below the scratch, formed as an integer)
+            const double *moved_back = reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(e->qb_chunk) - lo * kstride * sizeof(double));
+            ngd_launch_accum_mfma(e->st, g, e->PA, moved_back, wsel, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n,
+                                  per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, ks0);
+          }
           ks0 += n;
         }
       }
