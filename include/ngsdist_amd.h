@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 3 /* 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
+#define NGD_ABI_VERSION 4 /* 4: ngd_last_spill_timing; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
@@ -270,6 +270,25 @@ int ngd_drop_caches(ngd_engine *e);
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
+/* The accumulation phase of the last run that took the spilled-terms plan (EM path, bootstrap blocks too small for
+ * per-block partials: NGD_OPT_EM_SPILL), kernel by kernel, HIP events on the engine's stream summed over the job's chunks
+ * of sites -- for roofline accounting (bench.py --workload emboot).  All zero if the last run took another plan. */
+typedef struct ngd_spill_timing {
+  double ms_weights;          /* k_spill_weights + the memsets of a chunk's partial last k-group                     */
+  double ms_terms;            /* k_accum_em_table<SPILL>: the per-site EM (emOptim2.cpp:112-135), terms written       */
+  double ms_sanitize;         /* k_spill_sanitize (a no-op unless a term was not finite)                             */
+  double ms_contract;         /* k_contract_mfma: running sums += weights x terms                                    */
+  uint64_t chunks;            /* chunks of sites the job went through (NGD_OPT_EM_SPILL_BYTES)                       */
+  uint64_t sites;             /* sites visited                                                                       */
+  uint64_t unit_sites;        /* q: consecutive sites of one bootstrap block whose terms leave the EM kernel as one   */
+  uint64_t units;             /* K of the contraction = terms written and read per pair slot                         */
+  uint64_t slot_groups;       /* groups of 16 pair slots (N of the contraction / 16), padding included               */
+  uint64_t slot_groups_live;  /* ... of them written by the EM pass (hold at least one pair)                         */
+  uint64_t matrices;          /* matrices of the job                                                                 */
+  uint64_t matrix_groups;     /* groups of 16 matrices (M of the contraction / 16)                                   */
+  uint64_t contract_launches; /* k_contract_mfma launches (one per chunk and 128 matrices)                           */
+} ngd_spill_timing;
+int ngd_last_spill_timing(const ngd_engine *e, ngd_spill_timing *t);
 /* The shader clock (MHz) the last MFMA / table-driven EM accumulation launch ran at: one wavefront in the middle of
  * the grid reads the shader-cycle counter and the constant-rate counter around its work.  0 = not sampled (other
  * kernels).  For roofline accounting: a kernel's rate against the peak AT THE CLOCK THE CHIP HELD. */

@@ -369,20 +369,25 @@ constexpr int PACK_DENSE = NGD_PACK_DENSE;
 // each matrix; the slab holds RB planes per slice.  The RB x 8 accumulators take the registers of a second workgroup:
 // one workgroup per CU.
 //
-// SPILL: the per-site terms leave the kernel instead of being summed: term (pair slot p, site k) of the chunk of sites
-// [site_base, n_sites_eff) goes to slab[((k / 4) * n_pad + p / 16) * 64 + (k % 4) * 16 + p % 16] (n_pad = pair slots /
-// 16 here; pair slot = tile * 4096 + row * 64 + column) -- the fragment-major operand layout of ngd_internal.h with
-// "individual" = pair slot, so that contract_mfma.hip contracts the chunk with any number of bootstrap weight vectors
-// by FP64 MFMA.  Terms that are not finite (an all-zero individual: 0/0 in normalize(), as on the CPU) raise the flag
-// word `nanlist`; the chunk is then sanitised before it is contracted (0 x NaN must not reach the matrices that do
-// not draw the site).
+// SPILL: the terms leave the kernel instead of being summed over the slice.  A bootstrap replicate weights whole BLOCKS
+// of sites (rnd_map_data, ngsDist.cpp:416-437), so the terms of `spill_q` consecutive sites that share a block (a
+// divisor of the block size) are added up here first and leave as ONE term per (pair, unit): 1 / spill_q of the bytes
+// written, read and contracted.  Unit k of the chunk of sites [site_base, n_sites_eff) and pair slot p go to
+// slab[((k / 4) * n_pad + p / 16) * 64 + (k % 4) * 16 + p % 16] (n_pad = groups of 16 pair slots here) -- the
+// fragment-major operand layout of ngd_internal.h with "individual" = pair slot, so that contract_mfma.hip contracts the
+// chunk with any number of bootstrap weight vectors by FP64 MFMA.  Pair slots are dealt in groups of 16 consecutive
+// columns of one row of a tile, and only to groups that hold a pair: rowpg[tile * 64 + row] is the slot group of the
+// row's first live group (a diagonal tile's lower triangle and the columns beyond n_ind get none: 7.6 % of the groups
+// at 1000 individuals).  Terms that are not finite (an all-zero individual: 0/0 in normalize(), as on the CPU) raise
+// the flag word `nanlist`; the chunk is then sanitised before it is contracted (0 x NaN must not reach the matrices
+// that do not draw the site).
 template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK, int RB, bool SPILL = false>
 __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
     const double *__restrict__ PA, const uint32_t *__restrict__ ws, const double *__restrict__ Wb, ngd_score sc,
     const ngd_tile *__restrict__ tiles, uint32_t n_tiles, uint32_t n_ig, uint32_t n_pad, uint64_t n_ind,
     uint64_t n_sites_eff, uint64_t sites_per_slice, double *__restrict__ slab,
     unsigned long long *__restrict__ counters, uint64_t site_base = 0,
-    unsigned long long *__restrict__ nanlist = nullptr) {
+    unsigned long long *__restrict__ nanlist = nullptr, uint32_t spill_q = 1, const uint32_t *__restrict__ rowpg = nullptr) {
 
   constexpr int RPW = TS / NW;  // rows per wavefront
   constexpr int RS = em_tables<CH, PACK>::RS;
@@ -464,6 +469,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #endif
   // (a 32-bit count in a scalar register: as a 64-bit bound the compiler kept s1 in vector registers and spilled it)
   const uint32_t n_mine = s0 < s1 ? __builtin_amdgcn_readfirstlane((uint32_t)(s1 - s0)) : 0;
+  // SPILL: sites of the current unit worked so far, and the unit's index within the chunk
+  uint32_t in_unit = 0, unit_k = SPILL ? __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)ks * sites_per_slice) / (SPILL ? spill_q : 1u))) : 0;
   for (uint32_t si = 0; si < n_mine; si++) {
     const uint64_t s = s0 + si;
     double wgt = 1.0;
@@ -644,21 +651,35 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #endif
       if (*(const volatile __attribute__((address_space(3))) uint32_t *)&L.more[round & 1] == 0) { round++; break; }
     }
-    if constexpr (SPILL) {  // this site's 8 x 64 terms of the wavefront: four runs of 128 B per row
-      const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(s - site_base));
-      double *dst = slab + ((uint64_t)(k >> 2) * n_pad + (uint64_t)tile * 256 + wave * (RPW * 4)) * 64 + (k & 3) * 16;
-      const uint32_t loff = (lane >> 4) * 64 + (lane & 15);
-      bool bad = false;
+    if constexpr (SPILL) {
+      // the unit's last site (or the slice's): the wavefront's 8 x 64 sums leave, a run of 128 B per live group of 16
+      // columns (a slice starts at a unit boundary: sites_per_slice is a multiple of spill_q)
+      if (++in_unit == spill_q || si + 1 == n_mine) {
+        double *dst = slab + (uint64_t)(unit_k >> 2) * n_pad * 64 + (unit_k & 3) * 16 + (lane & 15);
+        const uint32_t grp = lane >> 4;
+        // (everything about the rows' slots is worked out HERE, from the lane's live mask and the slot map: hoisted out
+        // of the site loop it would hold registers through the search, which has none to spare)
+        uint32_t lv = live, row0 = tile * 64 + wave * RPW;
+        asm volatile("" : "+v"(lv), "+s"(row0));
+        bool bad = false;
 #pragma unroll
-      for (int r = 0; r < RPW; r++) {
-        const double c = acc[r][0];
-        bad = bad || !(__builtin_fabs(c) <= 1.7976931348623157e308);
-        dst[r * 256 + loff] = c;
-        acc[r][0] = 0;
+        for (int r = 0; r < RPW; r++) {
+          const double c = acc[r][0];
+          acc[r][0] = 0;
+          bad = bad || !(__builtin_fabs(c) <= 1.7976931348623157e308);
+          const unsigned long long rowmask = __builtin_amdgcn_ballot_w64((lv >> r) & 1);
+          if (rowmask) {  // (uniform) the row's live groups are g0 .. g1; dead pairs of a live group leave as 0.0
+            const uint32_t g0 = (uint32_t)__builtin_ctzll(rowmask) >> 4, g1 = (63u - (uint32_t)__builtin_clzll(rowmask)) >> 4;
+            const uint32_t base = rowpg[row0 + r];
+            if (grp >= g0 && grp <= g1) dst[(uint64_t)(base + grp - g0) * 64] = c;
+          }
+        }
+        // a term that is not finite (an all-zero individual: 0/0 in normalize(), as on the CPU): k_spill_sanitize
+        // (contract_mfma.hip) then goes over this chunk before it is contracted
+        if (bad) *(volatile unsigned long long *)nanlist = 1ull;
+        in_unit = 0;
+        unit_k++;
       }
-      // a term that is not finite (an all-zero individual: 0/0 in normalize(), as on the CPU): k_spill_sanitize
-      // (contract_mfma.hip) then goes over this chunk before it is contracted
-      if (bad) *(volatile unsigned long long *)nanlist = 1ull;
     }
   }
   if (tid == 0) {  // work done, for the roofline accounting of bench.py: (tile, site) visits and table rounds
@@ -744,18 +765,20 @@ void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const do
 #undef NGD_EMTB
 }
 
-// The terms of sites [s_lo, s_hi) of every pair slot, unsummed, into C (fragment-major, n_pg = n_tiles64 * 256 groups of
-// 16 pair slots per k-group of 4 sites; see the SPILL note at the kernel).  *d_nanflag is set to 1 if a term of the
-// chunk was not finite.
+// The terms of sites [s_lo, s_hi), added up over units of q consecutive sites, of every live pair slot into C
+// (fragment-major, n_pg groups of 16 pair slots per k-group of 4 units; see the SPILL note at the kernel; d_rowpg is the
+// slot group of every tile row's first live group).  sites_per_slice must be a multiple of q.  *d_nanflag is set to 1
+// if a term of the chunk was not finite.
 void ngd_launch_accum_em_table_spill(hipStream_t st, const ngd_geom &g, const double *PA, uint64_t s_lo, uint64_t s_hi,
                                      const ngd_score &score, int pairwise_del, const ngd_tile *d_tiles64,
-                                     uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, double *C,
-                                     unsigned long long *d_counters, unsigned long long *d_nanflag) {
+                                     uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, uint32_t q,
+                                     const uint32_t *d_rowpg, uint32_t n_pg, double *C, unsigned long long *d_counters,
+                                     unsigned long long *d_nanflag) {
   if (!n_tiles64 || s_hi <= s_lo) return;
 #define NGD_EMTS(P)                                                                                                      \
   hipLaunchKernelGGL((k_accum_em_table<8, 16, 4, false, P, true, 1, true>), dim3(n_tiles64 * n_ks), dim3(512), 0, st, PA, \
-                     nullptr, nullptr, score, d_tiles64, n_tiles64, g.n_ig, n_tiles64 * 256u, g.n_ind, s_hi,             \
-                     sites_per_slice, C, d_counters, s_lo, d_nanflag)
+                     nullptr, nullptr, score, d_tiles64, n_tiles64, g.n_ig, n_pg, g.n_ind, s_hi, sites_per_slice, C,      \
+                     d_counters, s_lo, d_nanflag, q, d_rowpg)
   if (pairwise_del) NGD_EMTS(true); else NGD_EMTS(false);
 #undef NGD_EMTS
 }

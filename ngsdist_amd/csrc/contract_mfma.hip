@@ -6,8 +6,11 @@
 // its weight does (the multiplicity of the site's block in the replicate's block map).  So the sums of ALL matrices of
 // a job are one contraction over sites,
 //     sum[r][pair] = SUM_s W[r][s] * c[pair][s],
-// with K = n_sites.  accum_em_table.hip (SPILL) writes c for a chunk of sites, unsummed, in the fragment-major operand
-// layout of ngd_internal.h ("individual" = pair slot, k = site of the chunk); k_spill_weights writes the chunk's
+// with K = n_sites -- or, since a replicate weights whole blocks of sites, K = the number of UNITS of q consecutive sites
+// of one block whose terms are added up before they leave the EM kernel (q = the block size, or a divisor of it: the
+// reference's own example of 10-site blocks moves a tenth of the bytes and flops of block size 1).
+// accum_em_table.hip (SPILL) writes c for a chunk of units in the fragment-major operand
+// layout of ngd_internal.h ("individual" = pair slot, k = unit of the chunk); k_spill_weights writes the chunk's
 // weights in the same layout ("individual" = matrix); k_contract_mfma multiplies the two with v_mfma_f64_16x16x4_f64
 // (A = weights: M = matrices, B = terms: N = pair slots) and adds the product to the job's running sums D, which a
 // wavefront owns for its block of (matrices x pair slots) -- chunks follow each other in stream order, so the order of
@@ -46,10 +49,11 @@ __device__ __forceinline__ double job_weight(const uint32_t *__restrict__ mult, 
   return (double)mult[(uint64_t)(r - (lead ? 1u : 0u)) * n_blocks + s / block_size];
 }
 
-// Wt[(kg * n_rg + rg) * 64 + (k & 3) * 16 + (r & 15)] = weight of site s_lo + k in matrix r0 + r, for the chunk's
-// k-groups 0 .. n_kg (one more than the chunk has: the contraction's operand fetch runs one k-group ahead)
+// Wt[(kg * n_rg + rg) * 64 + (k & 3) * 16 + (r & 15)] = weight of unit k (sites s_lo + k q .. + q - 1, one block) in
+// matrix r0 + r, for the chunk's k-groups 0 .. n_kg (one more than the chunk has: the contraction's operand fetch runs
+// one k-group ahead)
 __global__ __launch_bounds__(256) void k_spill_weights(const uint32_t *__restrict__ mult, uint32_t r0, uint32_t n_mat,
-                                                        int lead, uint64_t s_lo, uint64_t s_hi, uint64_t n_sites,
+                                                        int lead, uint64_t s_lo, uint64_t s_hi, uint32_t q, uint64_t n_sites,
                                                         uint64_t n_eff, uint64_t n_blocks, uint64_t block_size,
                                                         uint32_t n_rg, uint64_t n_frag, double *__restrict__ Wt) {
   const uint64_t f = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void k_spill_weights(const uint32_t *__restric
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t kg = f / n_rg;
   const uint32_t rg = (uint32_t)(f % n_rg);
-  const uint64_t s = s_lo + kg * 4 + (lane >> 4);
+  const uint64_t s = s_lo + (kg * 4 + (lane >> 4)) * q;  // the unit's first site
   const uint32_t r = r0 + rg * 16 + (lane & 15);
   Wt[f * 64 + lane] = s < s_hi ? job_weight(mult, r, n_mat, lead, s, n_sites, n_eff, n_blocks, block_size) : 0.0;
 }
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(256, 3) void k_contract_mfma(const double *__restri
 // of exactly the matrices that draw their site (NaN + anything stays NaN through the later chunks).
 __global__ __launch_bounds__(256) void k_spill_sanitize(double *__restrict__ C, const unsigned long long *__restrict__ flag,
                                                          uint64_t n_elems, uint32_t n_pg, const uint32_t *__restrict__ mult,
-                                                         uint32_t n_mat, int lead, uint64_t s_lo, uint64_t n_sites,
-                                                         uint64_t n_eff, uint64_t n_blocks, uint64_t block_size,
-                                                         double *__restrict__ D) {
+                                                         uint32_t n_mat, int lead, uint64_t s_lo, uint32_t q,
+                                                         uint64_t n_sites, uint64_t n_eff, uint64_t n_blocks,
+                                                         uint64_t block_size, double *__restrict__ D) {
   if (*flag == 0) return;
   for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_elems; x += (uint64_t)gridDim.x * blockDim.x) {
     const double c = C[x];
@@ -154,22 +158,26 @@ __global__ __launch_bounds__(256) void k_spill_sanitize(double *__restrict__ C, 
     const uint64_t frag = x >> 6;
     const uint32_t l = (uint32_t)(x & 63);
     const uint64_t kg = frag / n_pg, pg = frag % n_pg;
-    const uint64_t s = s_lo + kg * 4 + (l >> 4);
+    const uint64_t s = s_lo + (kg * 4 + (l >> 4)) * q;  // the unit's first site: its block is every site's of the unit
     for (uint32_t r = 0; r < n_mat; r++)
       if (job_weight(mult, r, n_mat, lead, s, n_sites, n_eff, n_blocks, block_size) != 0.0)
         D[d_tile_off(r >> 4, pg, n_pg) + ((r & 15) >> 2) * 64 + ((r & 3) << 4) + (l & 15)] = __builtin_nan("");
   }
 }
 
-// The job's sums leave D for the caller's [n_mat][n_pairs] arrays in the reference's pair order (ngsDist.cpp:244-245)
+// The job's sums leave D for the caller's [n_mat][n_pairs] arrays in the reference's pair order (ngsDist.cpp:244-245).
+// Pair slot of (row, column) of a tile: 16 * (rowpg[tile * 64 + row] + column / 16 - the row's first live group) + column % 16
 __global__ __launch_bounds__(256) void k_spill_scatter(const double *__restrict__ D, uint32_t n_pg,
-                                                        const ngd_tile *__restrict__ tiles, uint64_t n_ind,
-                                                        uint64_t n_pairs, uint32_t n_mat, double *__restrict__ d_sum) {
+                                                        const ngd_tile *__restrict__ tiles, const uint32_t *__restrict__ rowpg,
+                                                        uint64_t n_ind, uint64_t n_pairs, uint32_t n_mat,
+                                                        double *__restrict__ d_sum) {
   const uint32_t tile = blockIdx.x >> 4;
   const uint32_t slot = (blockIdx.x & 15) * 256 + threadIdx.x;  // within the 64 x 64 tile: row * 64 + column
-  const uint64_t i = (uint64_t)tiles[tile].ti * 64 + (slot >> 6), j = (uint64_t)tiles[tile].tj * 64 + (slot & 63);
+  const uint32_t row = slot >> 6, col = slot & 63;
+  const uint64_t i = (uint64_t)tiles[tile].ti * 64 + row, j = (uint64_t)tiles[tile].tj * 64 + col;
   if (i >= j || j >= n_ind) return;
-  const uint64_t p = (uint64_t)tile * 4096 + slot;
+  const uint32_t g0 = tiles[tile].ti == tiles[tile].tj ? (row + 1) >> 4 : 0;  // group of the row's first pair
+  const uint64_t p = ((uint64_t)rowpg[tile * 64 + row] + (col >> 4) - g0) * 16 + (col & 15);
   const uint64_t out = ngd_pair_idx(n_ind, i, j);
   for (uint32_t r = 0; r < n_mat; r++)
     d_sum[(uint64_t)r * n_pairs + out] =
@@ -181,20 +189,21 @@ __global__ __launch_bounds__(256) void k_spill_scatter(const double *__restrict_
 uint32_t ngd_contract_rep_groups(uint32_t n_mat) { return (n_mat + 15) / 16; }
 
 void ngd_launch_spill_weights(hipStream_t st, const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo,
-                              uint64_t s_hi, uint64_t n_sites, uint64_t n_eff, uint64_t n_blocks, uint64_t block_size,
-                              double *d_Wt) {
+                              uint64_t s_hi, uint32_t q, uint64_t n_sites, uint64_t n_eff, uint64_t n_blocks,
+                              uint64_t block_size, double *d_Wt) {
   const uint32_t n_rg = ngd_contract_rep_groups(n_mat);
-  const uint64_t n_kg = (s_hi - s_lo + 3) / 4 + 1;  // + the tail k-group of the operand run-ahead
+  const uint64_t n_units = (s_hi - s_lo + q - 1) / q;
+  const uint64_t n_kg = (n_units + 3) / 4 + 1;  // + the tail k-group of the operand run-ahead
   const uint64_t n_frag = n_kg * n_rg;
   hipLaunchKernelGGL(k_spill_weights, dim3((unsigned)((n_frag + 3) / 4)), dim3(256), 0, st, d_mult, 0u, n_mat, lead, s_lo,
-                     s_hi, n_sites, n_eff, n_blocks, block_size, n_rg, n_frag, d_Wt);
+                     s_hi, q, n_sites, n_eff, n_blocks, block_size, n_rg, n_frag, d_Wt);
 }
 
 void ngd_launch_spill_sanitize(hipStream_t st, double *C, const unsigned long long *d_flag, uint64_t n_kg, uint32_t n_pg,
-                               const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo, uint64_t n_sites,
+                               const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo, uint32_t q, uint64_t n_sites,
                                uint64_t n_eff, uint64_t n_blocks, uint64_t block_size, double *D) {
   hipLaunchKernelGGL(k_spill_sanitize, dim3(4096), dim3(256), 0, st, C, d_flag, n_kg * n_pg * 64, n_pg, d_mult, n_mat, lead,
-                     s_lo, n_sites, n_eff, n_blocks, block_size, D);
+                     s_lo, q, n_sites, n_eff, n_blocks, block_size, D);
 }
 
 // D += Wt x C over the chunk's n_kg k-groups, for all ngd_contract_rep_groups(n_mat) groups of 16 matrices
@@ -221,8 +230,8 @@ void ngd_launch_contract(hipStream_t st, const double *d_Wt, const double *C, ui
 }
 
 void ngd_launch_spill_scatter(hipStream_t st, const double *D, uint32_t n_pg, const ngd_tile *d_tiles64, uint32_t n_tiles64,
-                              uint64_t n_ind, uint32_t n_mat, double *d_sum) {
+                              const uint32_t *d_rowpg, uint64_t n_ind, uint32_t n_mat, double *d_sum) {
   if (!n_tiles64) return;
-  hipLaunchKernelGGL(k_spill_scatter, dim3(n_tiles64 * 16), dim3(256), 0, st, D, n_pg, d_tiles64, n_ind,
+  hipLaunchKernelGGL(k_spill_scatter, dim3(n_tiles64 * 16), dim3(256), 0, st, D, n_pg, d_tiles64, d_rowpg, n_ind,
                      n_ind * (n_ind - 1) / 2, n_mat, d_sum);
 }

@@ -127,6 +127,12 @@ struct ngd_engine {
   double *d_D = nullptr;
   unsigned long long *d_nanflag = nullptr;
   uint64_t cap_D = 0, cap_nanflag = 0;
+  // ... its pair slots: groups of 16 consecutive columns of one row of a 64 x 64 tile, dealt to the groups that hold a
+  // pair only; d_rowpg[tile * 64 + row] = slot group of the row's first live group, n_pg_spill = their number (+ padding to 4)
+  uint32_t *d_rowpg = nullptr;
+  uint32_t n_pg_spill = 0, n_pg_live = 0;
+  std::vector<hipEvent_t> ev_spill;  // per chunk: before the weights, the EM pass, the sanitiser, the contraction; + one at the end
+  ngd_spill_timing spill_timing{};
 };
 
 template <typename T>
@@ -202,7 +208,8 @@ void ngd_destroy(ngd_engine *e) {
   if (e->st) hipStreamSynchronize(e->st);
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
-                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag};
+                  e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag,
+                  e->d_rowpg};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -214,6 +221,8 @@ void ngd_destroy(ngd_engine *e) {
   if (e->d_nan) hipFree(e->d_nan);
   if (e->h_mult) hipHostFree(e->h_mult);
   for (auto &v : e->ev)
+    if (v) hipEventDestroy(v);
+  for (auto &v : e->ev_spill)
     if (v) hipEventDestroy(v);
   if (e->st) hipStreamDestroy(e->st);
   delete e;
@@ -587,6 +596,28 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
     TRY(dev_alloc(e, &e->d_emcnt, 4, true));
+    {
+      // pair slots of the spilled-terms plan (em_spill_impl): a row of a tile takes one slot group per group of 16 columns
+      // that holds a pair -- none for a diagonal tile's lower triangle or for the columns at and beyond n_ind
+      std::vector<uint32_t> rowpg((size_t)tiles64.size() * 64, 0xffffffffu);
+      uint64_t n_live = 0;
+      for (size_t t = 0; t < tiles64.size(); t++)
+        for (uint32_t row = 0; row < 64; row++) {
+          const uint64_t i = (uint64_t)tiles64[t].ti * 64 + row, j0 = (uint64_t)tiles64[t].tj * 64;
+          if (i >= g.n_ind || j0 >= g.n_ind) continue;
+          const uint64_t first = tiles64[t].ti == tiles64[t].tj ? row + 1 : 0, last = std::min<uint64_t>(63, g.n_ind - 1 - j0);
+          if (first > last) continue;
+          rowpg[t * 64 + row] = (uint32_t)n_live;
+          n_live += (last >> 4) - (first >> 4) + 1;
+        }
+      if (n_live + 4 < (1ull << 32)) {  // (else: the plan is not offered, em_spill_impl)
+        e->n_pg_live = (uint32_t)n_live;
+        e->n_pg_spill = (uint32_t)((n_live + 3) / 4 * 4);  // a wavefront of the contraction takes 2 or 4 slot groups
+        TRY(dev_alloc(e, &e->d_rowpg, rowpg.size(), false));
+        if (!rowpg.empty() && hipMemcpy(e->d_rowpg, rowpg.data(), rowpg.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+          return bail(fail(NGD_E_HIP, "ngd_create: slot map upload failed"));
+      }
+    }
   } else if (kernel == NGD_KERNEL_EM_FAST || kernel == NGD_KERNEL_EM_FAITHFUL) {
     uint64_t want = cfg->wg_target ? cfg->wg_target : 4096;
     uint64_t ks = e->n_tiles16 ? (want + e->n_tiles16 - 1) / e->n_tiles16 : 1;
@@ -1190,11 +1221,20 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
 }
 
 // EM path, many matrices, blocks too small for per-block partials: ONE pass of the table-driven EM kernel writes the
-// per-(pair, site) terms of a chunk of sites (they do not depend on the replicate), one FP64 MFMA contraction adds
-// the chunk to the running sums of every matrix of the job (contract_mfma.hip).  The chunk is as many sites as the
-// scratch budget holds (NGD_OPT_EM_SPILL_BYTES).  Outputs: [lead + n_rep][n_pairs]; every matrix agrees with its own
-// ngd_run() pass to rounding (the sums are formed in another order).  *done = false: the plan does not apply
-// (no room for a useful chunk) and nothing has been written.
+// per-(pair, unit of sites) terms of a chunk of sites (they do not depend on the replicate), one FP64 MFMA contraction
+// adds the chunk to the running sums of every matrix of the job (contract_mfma.hip).  A unit is q consecutive sites of
+// one bootstrap block (q = the block size or its largest divisor up to 64): every matrix weights them alike, so their
+// terms are added up before they leave the EM kernel -- the bytes written and read, and the flops of the contraction,
+// are those of n_sites / q.  The chunk is as many units as the scratch budget holds (NGD_OPT_EM_SPILL_BYTES).
+// Outputs: [lead + n_rep][n_pairs]; every matrix agrees with its own ngd_run() pass to rounding (the sums are formed in
+// another order).  *done = false: the plan does not apply (no room for a useful chunk) and nothing has been written.
+static uint32_t spill_unit(uint64_t block_size) {
+  uint32_t q = 1;
+  for (uint32_t d = 2; d <= 64 && d <= block_size; d++)
+    if (block_size % d == 0) q = d;
+  return q;
+}
+
 static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mult_max, const unsigned long long *drawn,
                          uint32_t n_rep, bool lead, uint64_t n_blocks, uint64_t block_size, double *d_sum,
                          unsigned long long *d_cnt, bool *done) {
@@ -1204,10 +1244,11 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   const uint64_t n_eff = n_blocks * block_size;
   const uint32_t n_mat = n_rep + (lead ? 1u : 0u);
   const uint32_t n_rg = ngd_contract_rep_groups(n_mat);
-  const uint64_t n_pg = (uint64_t)e->n_tiles64 * 256;  // groups of 16 pair slots
+  const uint64_t n_pg = e->n_pg_spill;  // groups of 16 pair slots (live groups only, padded to 4)
   const uint64_t s_end = lead ? g.n_sites : n_eff;
-  if (!e->n_tiles64 || n_pg >= (1ull << 32) || !s_end) return NGD_OK;
-  const uint64_t kg_bytes = n_pg * 64 * 8;  // one k-group (4 sites) of terms
+  if (!e->n_tiles64 || !n_pg || !e->d_rowpg || !s_end) return NGD_OK;
+  const uint32_t q = spill_unit(block_size);
+  const uint64_t kg_bytes = n_pg * 64 * 8;  // one k-group (4 units) of terms
   const uint64_t d_elems = (uint64_t)n_rg * n_pg * 256;
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1219,10 +1260,11 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   budget = std::min(budget, room);
   uint64_t chunk_kg = budget / kg_bytes;
   if (chunk_kg < 2) return NGD_OK;
-  chunk_kg = std::min<uint64_t>(chunk_kg - 1, (s_end + 3) / 4);  // (one k-group of tail for the operand run-ahead)
+  const uint64_t units_all = (s_end + q - 1) / q;
+  chunk_kg = std::min<uint64_t>(chunk_kg - 1, (units_all + 3) / 4);  // (one k-group of tail for the operand run-ahead)
   // chunks of a few sites are launch-bound: the plan is left to the others (unless the caller set the scratch size)
-  if (!e->opt_em_spill_bytes && chunk_kg * 4 < std::min<uint64_t>(s_end, 64)) return NGD_OK;
-  const uint64_t chunk_sites = chunk_kg * 4;
+  if (!e->opt_em_spill_bytes && chunk_kg * 4 * q < std::min<uint64_t>(s_end, 64)) return NGD_OK;
+  const uint64_t chunk_sites = chunk_kg * 4 * q;
   const uint64_t n_chunks = (s_end + chunk_sites - 1) / chunk_sites;
 
   e->boot_B = 0;  // the partial-sum slab is this plan's scratch
@@ -1236,6 +1278,11 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   if (rc) return rc;
   rc = ensure_cap(e, &e->d_nanflag, &e->cap_nanflag, n_chunks);
   if (rc) return rc;
+  while (e->ev_spill.size() < 4 * n_chunks + 1) {  // (kept for the engine's lifetime)
+    hipEvent_t v = nullptr;
+    HIPCHK(hipEventCreate(&v));
+    e->ev_spill.push_back(v);
+  }
   *done = true;
 
   HIPCHK(hipEventRecord(e->ev[0], e->st));
@@ -1247,38 +1294,49 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
     HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_mat * n_pairs * sizeof(unsigned long long), e->st));
   HIPCHK(hipEventRecord(e->ev[1], e->st));
   double *C = e->slab_boot;
+  uint64_t units_done = 0;
   for (uint64_t c = 0; c < n_chunks; c++) {
     const uint64_t s_lo = c * chunk_sites, s_hi = std::min(s_end, s_lo + chunk_sites);
-    const uint64_t len = s_hi - s_lo, n_kg = (len + 3) / 4;
-    if (len & 3) HIPCHK(hipMemsetAsync(C + (n_kg - 1) * n_pg * 64, 0, kg_bytes, e->st));  // the last k-group is partial
-    ngd_launch_spill_weights(e->st, e->d_M, n_mat, lead ? 1 : 0, s_lo, s_hi, g.n_sites, n_eff, n_blocks, block_size, e->d_W);
-    // slices of the chunk's sites: enough workgroups to fill the device a few times over, a few sites each at least
+    const uint64_t len = s_hi - s_lo, n_units = (len + q - 1) / q, n_kg = (n_units + 3) / 4;
+    units_done += n_units;
+    hipEvent_t *ev = &e->ev_spill[4 * c];
+    HIPCHK(hipEventRecord(ev[0], e->st));
+    if (n_units & 3) HIPCHK(hipMemsetAsync(C + (n_kg - 1) * n_pg * 64, 0, kg_bytes, e->st));  // the last k-group is partial
+    if (n_pg > e->n_pg_live)  // the slot groups of padding, which no wavefront of the EM pass writes
+      HIPCHK(hipMemset2DAsync(C + (uint64_t)e->n_pg_live * 64, kg_bytes, 0, (n_pg - e->n_pg_live) * 512, n_kg, e->st));
+    ngd_launch_spill_weights(e->st, e->d_M, n_mat, lead ? 1 : 0, s_lo, s_hi, q, g.n_sites, n_eff, n_blocks, block_size, e->d_W);
+    HIPCHK(hipEventRecord(ev[1], e->st));
+    // slices of the chunk's sites (whole units): enough workgroups to fill the device a few times over, a few sites each
+    // at least
     uint64_t ks = std::max<uint64_t>(1, std::min<uint64_t>((8192 + e->n_tiles64 - 1) / e->n_tiles64, len / 8));
-    const uint64_t sps = (len + ks - 1) / ks;
+    const uint64_t sps = ((len + ks - 1) / ks + q - 1) / q * q;
     ks = (len + sps - 1) / sps;
     ngd_launch_accum_em_table_spill(e->st, g, e->PA, s_lo, s_hi, e->sc, e->cfg.pairwise_del, e->d_tiles64, e->n_tiles64,
-                                    (uint32_t)ks, sps, C, e->d_emcnt, e->d_nanflag + c);
-    ngd_launch_spill_sanitize(e->st, C, e->d_nanflag + c, n_kg, (uint32_t)n_pg, e->d_M, n_mat, lead ? 1 : 0, s_lo,
+                                    (uint32_t)ks, sps, q, e->d_rowpg, (uint32_t)n_pg, C, e->d_emcnt, e->d_nanflag + c);
+    HIPCHK(hipEventRecord(ev[2], e->st));
+    ngd_launch_spill_sanitize(e->st, C, e->d_nanflag + c, n_kg, (uint32_t)n_pg, e->d_M, n_mat, lead ? 1 : 0, s_lo, q,
                               g.n_sites, n_eff, n_blocks, block_size, e->d_D);
+    HIPCHK(hipEventRecord(ev[3], e->st));
     ngd_launch_contract(e->st, e->d_W, C, n_mat, (uint32_t)n_pg, (uint32_t)n_kg, e->d_D);
     HIPCHK(hipGetLastError());
   }
+  HIPCHK(hipEventRecord(e->ev_spill[4 * n_chunks], e->st));
   HIPCHK(hipEventRecord(e->ev[2], e->st));
-  ngd_launch_spill_scatter(e->st, e->d_D, (uint32_t)n_pg, e->d_tiles64, e->n_tiles64, g.n_ind, n_mat, d_sum);
+  ngd_launch_spill_scatter(e->st, e->d_D, (uint32_t)n_pg, e->d_tiles64, e->n_tiles64, e->d_rowpg, g.n_ind, n_mat, d_sum);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   for (uint32_t r = 0; r < n_mat; r++) {
     unsigned long long *cnt_r = d_cnt + (uint64_t)r * n_pairs;
     const bool is_lead = lead && r == 0;
-    const uint32_t q = r - (lead ? 1u : 0u);
+    const uint32_t qr = r - (lead ? 1u : 0u);
     if (!e->cfg.pairwise_del) {
-      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[q], nullptr, 1, cnt_r);
+      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[qr], nullptr, 1, cnt_r);
     } else if (is_lead) {
       ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles, e->n_tiles, cnt_r);
     } else {
       uint32_t n_planes = 0;
-      while (n_planes < 32 && (mult_max[q] >> n_planes)) n_planes++;
+      while (n_planes < 32 && (mult_max[qr] >> n_planes)) n_planes++;
       if (!n_planes) n_planes = 1;  // (as in pass_impl: a replicate that drew none of these blocks counts 0 sites)
-      ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)q * n_blocks, e->d_ws, nullptr);
+      ngd_launch_weights(e->st, n_blocks, block_size, g.n_sites_pad, e->d_M + (uint64_t)qr * n_blocks, e->d_ws, nullptr);
       ngd_launch_planes(e->st, e->d_ws, g.n_sites, g.n_words, n_planes, e->planes);
       ngd_launch_count(e->st, g, e->mask, e->planes, n_planes, e->d_tiles, e->n_tiles, cnt_r);
     }
@@ -1287,6 +1345,18 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));  // `mult` is the caller's host memory
   read_timing(e, s_end, 1, false);
+  {  // where the accumulation phase went, kernel by kernel (ngd_last_spill_timing)
+    ngd_spill_timing &t = e->spill_timing;
+    t = ngd_spill_timing{};
+    for (uint64_t c = 0; c < n_chunks; c++) {
+      float ms[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4; k++) hipEventElapsedTime(&ms[k], e->ev_spill[4 * c + k], e->ev_spill[4 * c + k + 1]);
+      t.ms_weights += ms[0]; t.ms_terms += ms[1]; t.ms_sanitize += ms[2]; t.ms_contract += ms[3];
+    }
+    t.chunks = n_chunks; t.units = units_done; t.unit_sites = q; t.sites = s_end;
+    t.slot_groups = n_pg; t.slot_groups_live = e->n_pg_live; t.matrices = n_mat; t.matrix_groups = n_rg;
+    t.contract_launches = n_chunks * ((n_rg + 7) / 8);
+  }
   return NGD_OK;
 }
 
@@ -1300,6 +1370,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   if (!e->committed) return fail(NGD_E_INVALID, "ngd_run: call ngd_commit() first");
   HIPCHK(hipSetDevice(e->device));
   const ngd_geom &g = e->g;
+  e->spill_timing = ngd_spill_timing{};
   if (!n_rep) return pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
 
   if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
@@ -1577,6 +1648,12 @@ int ngd_last_em_work(const ngd_engine *e, uint64_t *tile_sites, uint64_t *table_
 int ngd_last_shader_clock(const ngd_engine *e, double *mhz) {
   if (!e || !mhz) return fail(NGD_E_INVALID, "ngd_last_shader_clock: null argument");
   *mhz = e->clk_mhz;
+  return NGD_OK;
+}
+
+int ngd_last_spill_timing(const ngd_engine *e, ngd_spill_timing *t) {
+  if (!e || !t) return fail(NGD_E_INVALID, "ngd_last_spill_timing: null argument");
+  *t = e->spill_timing;
   return NGD_OK;
 }
 

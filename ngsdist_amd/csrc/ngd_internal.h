@@ -140,25 +140,29 @@ void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const do
                                      const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t n_ks,
                                      uint64_t sites_per_slice, double *slab, unsigned long long *d_counters);
 
-// accum_em_table.hip, terms unsummed: sites [s_lo, s_hi) of every pair slot into C (fragment-major: k-groups of 4 sites
-// x n_tiles64 * 256 groups of 16 pair slots); *d_nanflag = 1 if a term was not finite
+// accum_em_table.hip, terms not summed over the slice: sites [s_lo, s_hi) in units of q consecutive sites (one term per
+// pair slot and unit) into C (fragment-major: k-groups of 4 units x n_pg groups of 16 pair slots; d_rowpg[tile * 64 + row] =
+// slot group of the row's first live group of 16 columns, ngd_spill_slot_groups()); *d_nanflag = 1 if a term was not finite
 void ngd_launch_accum_em_table_spill(hipStream_t st, const ngd_geom &g, const double *PA, uint64_t s_lo, uint64_t s_hi,
                                      const ngd_score &score, int pairwise_del, const ngd_tile *d_tiles64,
-                                     uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, double *C,
-                                     unsigned long long *d_counters, unsigned long long *d_nanflag);
+                                     uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, uint32_t q,
+                                     const uint32_t *d_rowpg, uint32_t n_pg, double *C, unsigned long long *d_counters,
+                                     unsigned long long *d_nanflag);
 
-// contract_mfma.hip : running sums D[matrix][pair slot] += W[matrix][site] * C[site][pair slot] over a chunk of sites
+// contract_mfma.hip : running sums D[matrix][pair slot] += W[matrix][unit] * C[unit][pair slot] over a chunk of sites
+// (a unit = q consecutive sites of one bootstrap block; site s_lo is the first site of the chunk's unit 0)
 uint32_t ngd_contract_rep_groups(uint32_t n_mat);  // groups of 16 matrices
 void ngd_launch_spill_weights(hipStream_t st, const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo,
-                              uint64_t s_hi, uint64_t n_sites, uint64_t n_eff, uint64_t n_blocks, uint64_t block_size,
-                              double *d_Wt);
+                              uint64_t s_hi, uint32_t q, uint64_t n_sites, uint64_t n_eff, uint64_t n_blocks,
+                              uint64_t block_size, double *d_Wt);
 void ngd_launch_spill_sanitize(hipStream_t st, double *C, const unsigned long long *d_flag, uint64_t n_kg, uint32_t n_pg,
-                               const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo, uint64_t n_sites,
+                               const uint32_t *d_mult, uint32_t n_mat, int lead, uint64_t s_lo, uint32_t q, uint64_t n_sites,
                                uint64_t n_eff, uint64_t n_blocks, uint64_t block_size, double *D);
+// n_pg must be a multiple of 4 (ngd_create pads the slot groups)
 void ngd_launch_contract(hipStream_t st, const double *d_Wt, const double *C, uint32_t n_mat, uint32_t n_pg, uint32_t n_kg,
                          double *D);
 void ngd_launch_spill_scatter(hipStream_t st, const double *D, uint32_t n_pg, const ngd_tile *d_tiles64, uint32_t n_tiles64,
-                              uint64_t n_ind, uint32_t n_mat, double *d_sum);
+                              const uint32_t *d_rowpg, uint64_t n_ind, uint32_t n_mat, double *d_sum);
 
 // rb (4, 8 or 16) replicates in one pass; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
 void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,

@@ -234,6 +234,12 @@ class Engine:
         _check(self._L.ngd_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def spill_timing(self):
+        """the spilled-terms plan's accumulation phase kernel by kernel (ngd_last_spill_timing); zeros after another plan"""
+        t = _lib.NgdSpillTiming()
+        _check(self._L.ngd_last_spill_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
     def em_work(self):
         """table-driven EM kernel: ((tile, site) visits, table rounds) of the last run"""
         a, b = C.c_uint64(0), C.c_uint64(0)

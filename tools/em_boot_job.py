@@ -48,8 +48,17 @@ with N.Engine(a.n_ind, a.n_sites, indep_geno=False, kernel="em_table", pairwise_
             e.run_job(maps, a.block)  # (allocations)
             t = time.perf_counter(); S, C = e.run_job(maps, a.block); job = (time.perf_counter() - t) * 1e3
             tm = e.timing()
+            sp = e.spill_timing()
             print("  %3d replicates of %d-site blocks + the full-data matrix, %-12s: %7.0f ms (%.2f plain passes; device "
                   "%.0f ms: accumulate %.0f, scatter/reduce %.1f); last replicate vs its own pass %.1e, matrix 0 vs the "
                   "plain pass %.1e, counts equal: %s"
                   % (n_rep, a.block, name, job, job / plain, tm["ms_total"], tm["ms_accum"], tm["ms_reduce"],
                      rel(S[-1], s1), rel(S[0], s0), np.array_equal(C[-1], c1) and np.array_equal(C[0], c0)), flush=True)
+            if sp["chunks"]:
+                tb = sp["units"] * sp["slot_groups_live"] * 16 * 8  # bytes of terms written once and read once per 128 matrices
+                fl = 2.0 * sp["units"] * sp["slot_groups"] * 16 * sp["matrix_groups"] * 16
+                print("        %d chunks, units of %d sites: EM pass %.1f ms, contraction %.1f ms (%.2f TB/s of terms, %.1f TF), "
+                      "weights %.1f, sanitize %.1f; %d of %d slot groups live"
+                      % (sp["chunks"], sp["unit_sites"], sp["ms_terms"], sp["ms_contract"],
+                         tb * ((sp["matrix_groups"] + 7) // 8) / sp["ms_contract"] / 1e9, fl / sp["ms_contract"] / 1e9,
+                         sp["ms_weights"], sp["ms_sanitize"], sp["slot_groups_live"], sp["slot_groups"]), flush=True)
