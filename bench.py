@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- pair-distances/s of the gen_dist() hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5] [--kernel ...]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg5|emboot] [--kernel ...]
 
 One "step" = one job of the hot path over the resident data set: accumulation
 kernel(s) -> deterministic slab reduction -> copy to host -> /cnt and
@@ -53,6 +53,13 @@ WORKLOADS = {
     "cfg3": dict(n_ind=1000, n_sites=1_000_000, indep=True, evol_model=1, seed=3, n_boot=0, block=1),
     "cfg4": dict(n_ind=1000, n_sites=1_000_000, indep=False, evol_model=2, seed=3, n_boot=0, block=1),
     "cfg5": dict(n_ind=500, n_sites=500_000, indep=True, evol_model=1, seed=5, n_boot=64, block=1000),
+    # The reference's own kind of bootstrap run (examples/test.sh:24-25: the EM path, --n_boot_rep, --boot_block_size 10;
+    # parse_args.cpp:29-31) at cfg 4's shape on 1e5 sites: 101 matrices from ONE pass of the per-site EM -- the terms of
+    # every (pair, unit of 10 sites) spilled once, one FP64 MFMA contraction with every matrix's weights (em_spill_impl).
+    # Per-block partial results are switched off (10 000 blocks x 8.4 MB = an 84 GB slab, which the engine only buys after
+    # a few jobs have paid its allocation): this is the plan a single job gets.  --n_boot / --block vary the job.
+    "emboot": dict(n_ind=1000, n_sites=100_000, indep=False, evol_model=2, seed=3, n_boot=100, block=10,
+                   options={"boot_partials": 0}),
 }
 
 
@@ -73,6 +80,43 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def host_cpu():
+    """The host the cpu_baseline leg runs on (north_star: "the reference's --n_threads CPU path timed on the GPU box's own
+    host cores, core count stated"): logical cores of the box, the CPU model, and the cores THIS process may use -- its
+    affinity mask cut down to the container's CPU quota (cgroup cpu.max) where there is one -- which is the thread count
+    the baseline takes (the reference clamps --n_threads to the number of pairs, ngsDist.cpp:44-52)."""
+    info = {"host_cores": os.cpu_count() or 1, "cpu_model": None, "affinity_cores": None, "cgroup_cpu_quota": None}
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                info["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        info["affinity_cores"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            parts = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if parts[0] != "max":
+                    info["cgroup_cpu_quota"] = float(parts[0]) / float(parts[1])
+            else:
+                q = float(parts[0])
+                if q > 0:
+                    info["cgroup_cpu_quota"] = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = info["affinity_cores"] or info["host_cores"]
+    if info["cgroup_cpu_quota"]:
+        usable = max(1, min(usable, int(info["cgroup_cpu_quota"] + 0.5)))
+    info["threads"] = int(usable)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +125,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
+    ap.add_argument("--n_boot", type=int, default=-1, help="override the workload's --n_boot_rep (bootstrap workloads)")
+    ap.add_argument("--block", type=int, default=0, help="override the workload's --boot_block_size (bootstrap workloads)")
     ap.add_argument("--single_image", type=int, nargs="?", const=1, default=0,
                     help="ngd_config.single_image: hold one operand image -- 1: the other formed a range of sites at a time "
                          "(memory for time), 2: both operands from one image in congruent coordinates")
@@ -92,6 +138,8 @@ def main():
                     help="ngd_config.exact_shapes: the MFMA kernel's block form (0 = the engine's choice; experiments)")
     ap.add_argument("--cpu_sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu_threads", type=int, default=0,
+                    help="threads of the cpu_baseline leg (0 = every core this process may use: affinity mask and cgroup quota)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -162,6 +210,11 @@ def main():
     W = dict(WORKLOADS[args.workload])
     if args.n_sites:
         W["n_sites"] = args.n_sites
+    if args.n_boot >= 0 or args.block:
+        if not W["n_boot"]:
+            raise SystemExit("bench.py: --n_boot / --block vary a bootstrap workload (cfg5, emboot)")
+        W["n_boot"] = args.n_boot if args.n_boot > 0 else W["n_boot"]
+        W["block"] = args.block or W["block"]
     n_ind, n_sites = W["n_ind"], W["n_sites"]
     n_pairs = N.n_pairs(n_ind)
     kernel = args.kernel
@@ -205,6 +258,8 @@ def main():
         eng.synth_fill(W["seed"], args.miss_frac)
     if args.single_image == 1 and args.single_image_gb > 0:
         eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
+    for name, v in W.get("options", {}).items():
+        eng.set_option(name, v)
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
@@ -216,6 +271,7 @@ def main():
              for m in maps]
 
     acc_ms, red_ms, tot_ms, pair_sites = [], [], [], []
+    spill_t = []  # emboot: the accumulation phase kernel by kernel, per timed step (ngd_last_spill_timing)
     last = {}
     on_gpu = args.backend == "nccl"  # collectives on device tensors (RCCL) or, in the rehearsal, on host tensors (gloo)
     pin = lambda *shape: torch.empty(*shape, dtype=torch.float64).pin_memory()
@@ -338,6 +394,9 @@ def main():
         red_ms.append(t["ms_reduce"]); tot_ms.append(t["ms_total"])
         if t["launches"]:  # replicates served from cached block partial sums launch no accumulation
             acc_ms.append(t["ms_accum"] / t["launches"]); pair_sites.append(t["pair_sites"] / t["launches"])
+        sp = eng.spill_timing()
+        if sp["chunks"]:
+            spill_t.append(sp)
 
     def step(record, variant=0):
         eng.drop_caches()  # bootstrap block partial sums are recomputed in every step (no carried work)
@@ -602,15 +661,20 @@ def main():
                 k += 1
         spot = {"pairs": k, "sites": int(n_eff if src is not None else n_sites), "max_rel_err_vs_oracle": float(worst)}
         if not args.no_cpu and world == 1:  # the CPU baseline is an N=1 figure
-            cores = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
-            rate_guess = (1.7e8 if W["indep"] else 2.8e6) * cores  # pair-sites/s per thread, measured
-            cs = args.cpu_sites or int(max(64, min(n_sites, 15.0 * rate_guess / n_pairs)))
+            hc = host_cpu()
+            # every core this process may use (ngsDist.cpp:44-52: --n_threads); the port's pool holds up to 256 threads
+            cores = min(args.cpu_threads or hc["threads"], 256)
+            rate_guess = (1.7e8 if W["indep"] else 2.8e6) * min(cores, 64)  # pair-sites/s per thread, measured
+            # ~15 s of wall time at the measured per-thread rate, the sample held to 2 GB of likelihoods
+            cs = args.cpu_sites or int(max(64, min(n_sites, 15.0 * rate_guess / n_pairs, 2e9 / (24.0 * n_ind))))
             pc = O.synth_indmajor(W["seed"], n_ind, cs)
             tc = time.perf_counter()
             O.all_pairs(pc, indep_geno=W["indep"], n_threads=cores)
             tc = time.perf_counter() - tc
             cpu_ps = n_pairs * cs / tc
             cpu = {"value": cpu_ps / n_sites, "unit": "pair-distances/s", "cores": cores, "kind": "port",
+                   "threads": cores, "host_cores": hc["host_cores"], "cpu_model": hc["cpu_model"],
+                   "affinity_cores": hc["affinity_cores"], "cgroup_cpu_quota": hc["cgroup_cpu_quota"],
                    "pair_sites_per_s": cpu_ps, "seconds": tc,
                    "sample": "first %d of %d sites, all %d pairs, same generator/seed; rate scaled linearly "
                              "in n_sites to one full matrix" % (cs, n_sites, n_pairs)}
@@ -632,7 +696,8 @@ def main():
                     sp, _ = O.all_pairs(pr, indep_geno=False, n_threads=cores)
                     ref_ps = n_pairs * cr / tr
                     cpu["reference_em2"] = {
-                        "value": ref_ps / n_sites, "unit": "pair-distances/s", "cores": cores, "kind": "reference-em2",
+                        "value": ref_ps / n_sites, "unit": "pair-distances/s", "cores": cores, "threads": cores,
+                        "host_cores": hc["host_cores"], "cpu_model": hc["cpu_model"], "kind": "reference-em2",
                         "pair_sites_per_s": ref_ps, "seconds": tr, "bit_identical_to_port": bool(np.array_equal(sr, sp)),
                         "sample": "first %d of %d sites, all %d pairs: gen_dist's loop as restated in oracle/, em2() the "
                                   "reference's own (emOptim2.cpp:112-135); rate scaled linearly in n_sites"
@@ -673,6 +738,14 @@ def main():
         # reports as table rounds per (tile, site) and which is fixed at its measured mean for the per-pair kernels.
         ps_launch = pair_sites_per_launch_all / world
         lane_peak = PEAK_FP64_TFLOPS * 1e12 / 2  # FP64 lane-instruction slots per second (1 slot = 1 FMA = 2 flop)
+        spill = None
+        if spill_t:
+            # the spilled-terms plan: the dominant kernel is the EM pass itself (k_accum_em_table<SPILL>, one launch per chunk
+            # of sites), priced like cfg 4's; the contraction that follows every chunk has its own roofline below
+            spill = {k: float(np.mean([x[k] for x in spill_t])) for k in spill_t[0]}
+            acc_job_ms = acc_mean_ms
+            acc_mean_ms = spill["ms_terms"] / spill["chunks"]
+            t_acc = spill["ms_terms"] * 1e-3
         roof = {"bound": "valu", "kernel": "k_accum_%s" % kernel, "achieved": None, "peak": lane_peak,
                 "unit": "lane-instructions/s", "frac": None, "traffic": None, "ms_per_launch": acc_mean_ms,
                 "pair_sites_per_s": ps_launch / t_acc,
@@ -701,6 +774,39 @@ def main():
                 roof["valu_stale"] = "measured on another version of %s" % src
         except Exception as exc:
             roof["frac_kind"] = "no PMC pass of this kernel under profiles/ (%r)" % (exc,)
+        if spill:
+            # k_contract_mfma: running sums D[matrix][pair slot] += W[matrix][unit] x C[unit][pair slot] per chunk.  Algorithmic
+            # bytes: every term read once per batch of 128 matrices, the running sums read and written once per chunk, the
+            # weights; algorithmic flops: 2 per (matrix of the padded groups of 16, pair slot, unit).  Whichever of the two
+            # takes longer at its peak is the bound: HBM up to ~32 matrices, the FP64 matrix pipe above.
+            mg, sg, sgl, un, ch = (spill[k] for k in ("matrix_groups", "slot_groups", "slot_groups_live", "units", "chunks"))
+            term_bytes = un * sgl * 16 * 8
+            c_bytes = term_bytes * np.ceil(mg / 8) + 2 * 8 * mg * sg * 256 * ch + (un + 4 * ch) * mg * 16 * 8
+            c_flops = 2.0 * (16 * mg) * (16 * sg) * un
+            t_c = spill["ms_contract"] * 1e-3
+            c_hbm, c_mf = c_bytes / t_c / 1e9, c_flops / t_c / 1e12
+            by_hbm = c_hbm / PEAK_HBM_GBS >= c_mf / PEAK_FP64_TFLOPS
+            roof["ms_per_job"] = spill["ms_terms"]
+            roof["launches_per_job"] = ch
+            roof["instantiation"] = "k_accum_em_table<8, 16, 4, false, PDEL, true, 1, SPILL = true>"
+            roof["terms_written_bytes_per_job"] = term_bytes
+            roof["spill"] = dict(spill, ms_accumulation_phase=acc_job_ms,
+                                 note="ms_*: HIP events on the engine's stream around each kernel, summed over the job's chunks, "
+                                      "mean over the timed steps; a unit = unit_sites consecutive sites of one bootstrap block, "
+                                      "whose terms are added up before they leave the EM kernel")
+            roof["contract"] = {
+                "kernel": "k_contract_mfma", "bound": "hbm" if by_hbm else "mfma",
+                "achieved": c_hbm if by_hbm else c_mf, "peak": PEAK_HBM_GBS if by_hbm else PEAK_FP64_TFLOPS,
+                "unit": "GB/s" if by_hbm else "TFLOP/s",
+                "frac": c_hbm / PEAK_HBM_GBS if by_hbm else c_mf / PEAK_FP64_TFLOPS,
+                "hbm": {"achieved": c_hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": c_hbm / PEAK_HBM_GBS},
+                "mfma": {"achieved": c_mf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": c_mf / PEAK_FP64_TFLOPS},
+                "ms_per_job": spill["ms_contract"], "ms_per_launch": spill["ms_contract"] / spill["contract_launches"],
+                "traffic": None,
+                "algorithmic": "%.4g B per job: %.4g B of terms (%d units x %d live pair slots x 8 B) read once per 128 matrices, "
+                               "the running sums (%d x %d x 8 B) read and written once per chunk (%d), the weights; %.4g flop = "
+                               "2 x %d matrices (padded to 16s) x %d pair slots x %d units"
+                               % (c_bytes, term_bytes, un, sgl * 16, 16 * mg, 16 * sg, ch, c_flops, 16 * mg, 16 * sg, un)}
         if kernel == "em_table":
             tile_sites, rounds = eng.em_work()
             roof["table_rounds_per_tile_site"] = rounds / max(1, tile_sites)
@@ -727,17 +833,23 @@ def main():
             roof["traffic_stale"] = "profiles/%s was measured on another version of %s" % (tname, src)
         else:
             for kname, v in tj["per_launch"].items():
-                if "accum" in kname:
+                if "accum" in kname and roof.get("traffic") is None:
                     roof["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
                     roof["traffic_source"] = "profiles/%s (%s)" % (tname, tj["source"])
-                    break
+                if "contract" in kname and "contract" in roof:
+                    roof["contract"]["traffic"] = v.get("read_bytes", 0) + v.get("write_bytes", 0)
+                    roof["contract"]["traffic_source"] = "profiles/%s (%s), per launch" % (tname, tj["source"])
     except Exception:
         pass
 
     # the dominant kernel's launches inside the timed region (HIP events on the engine's stream) and the shader clock
     # the device reported meanwhile: what a rocprofv3 pass of this command must reproduce (tools/profile.sh keeps its
     # kernel trace only if its own ms_per_step is within 2 % of an unprofiled line of the same lease)
-    if acc_ms:
+    if spill_t:
+        per = [x["ms_terms"] / x["chunks"] for x in spill_t]
+        roof["ms_per_launch_min"], roof["ms_per_launch_median"] = float(np.min(per)), float(np.median(per))
+        roof["launches_timed"] = int(sum(x["chunks"] for x in spill_t))
+    elif acc_ms:
         roof["ms_per_launch_min"], roof["ms_per_launch_median"] = float(np.min(acc_ms)), float(np.median(acc_ms))
         roof["launches_timed"] = len(acc_ms)
     # the clock the dominant kernel ran at, sampled INSIDE its last launch (one wavefront reads the shader-cycle and the

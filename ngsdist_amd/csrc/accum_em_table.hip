@@ -376,9 +376,9 @@ constexpr int PACK_DENSE = NGD_PACK_DENSE;
 // slab[((k / 4) * n_pad + p / 16) * 64 + (k % 4) * 16 + p % 16] (n_pad = groups of 16 pair slots here) -- the
 // fragment-major operand layout of ngd_internal.h with "individual" = pair slot, so that contract_mfma.hip contracts the
 // chunk with any number of bootstrap weight vectors by FP64 MFMA.  Pair slots are dealt in groups of 16 consecutive
-// columns of one row of a tile, and only to groups that hold a pair: rowpg[tile * 64 + row] is the slot group of the
-// row's first live group (a diagonal tile's lower triangle and the columns beyond n_ind get none: 7.6 % of the groups
-// at 1000 individuals).  Terms that are not finite (an all-zero individual: 0/0 in normalize(), as on the CPU) raise
+// columns of one row of a tile, and only to groups that hold a pair: rowpg[tile * 64 + row] + g is the slot group of the
+// row's column group g (a diagonal tile's lower triangle and the columns beyond n_ind get none: 7.6 % of the groups
+// at 1000 individuals; rowpg is the first live group's slot group minus that group's index).  Terms that are not finite (an all-zero individual: 0/0 in normalize(), as on the CPU) raise
 // the flag word `nanlist`; the chunk is then sanitised before it is contracted (0 x NaN must not reach the matrices
 // that do not draw the site).
 template <int NW, int CH, int WPS, bool WEIGHTED, bool PDEL, bool PACK, int RB, bool SPILL = false>
@@ -424,6 +424,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
 #pragma unroll
   for (int r = 0; r < RPW; r++)
     if (I0 + wave * RPW + r < j && j < n_ind) live |= 1u << r;
+  if constexpr (SPILL) {  // bit 8 + r: this lane's group of 16 columns holds a pair of row r (the groups that get pair slots)
+    static_assert(RPW == 8, "live: 8 row bits + 8 group bits");
+    uint32_t gl = 0;
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64((live >> r) & 1);
+      if ((m >> (lane & 48)) & 0xffffull) gl |= 1u << (8 + r);
+    }
+    live |= gl;
+  }
   double acc[RPW][RB];
 #pragma unroll
   for (int r = 0; r < RPW; r++)
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
         poison |= nz;
       }
     }
-    uint32_t todo = live;
+    uint32_t todo = SPILL ? live & 0xffu : live;
     sites_done++;
     EMT_STAMP(2);  // per-site set-up (powers)
     // (every pair has stopped by step MAX_ITER, where the tables force it: the bound only restates that)
@@ -655,24 +665,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void k_accum_em_table(
       // the unit's last site (or the slice's): the wavefront's 8 x 64 sums leave, a run of 128 B per live group of 16
       // columns (a slice starts at a unit boundary: sites_per_slice is a multiple of spill_q)
       if (++in_unit == spill_q || si + 1 == n_mine) {
-        double *dst = slab + (uint64_t)(unit_k >> 2) * n_pad * 64 + (unit_k & 3) * 16 + (lane & 15);
-        const uint32_t grp = lane >> 4;
-        // (everything about the rows' slots is worked out HERE, from the lane's live mask and the slot map: hoisted out
-        // of the site loop it would hold registers through the search, which has none to spare)
-        uint32_t lv = live, row0 = tile * 64 + wave * RPW;
-        asm volatile("" : "+v"(lv), "+s"(row0));
+        // one store per row: the row's slot base is wave-uniform (scalar base + the lane's offset in its group), the lanes
+        // of groups without a pair are masked off (bits 8.. of `live`); dead pairs of a live group leave as 0.0
+        double *dunit = slab + (uint64_t)(unit_k >> 2) * n_pad * 64 + (unit_k & 3) * 16;
+        const uint32_t loff = (lane >> 4) * 64 + (lane & 15);
+        uint32_t row0 = tile * 64 + wave * RPW;
+        asm volatile("" : "+s"(row0));  // the rows' slot bases are fetched HERE (one scalar load of 32 B): held through the
+                                        // site loop they would take 8 scalar registers from the search, which spills then
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < RPW; r++) {
           const double c = acc[r][0];
           acc[r][0] = 0;
           bad = bad || !(__builtin_fabs(c) <= 1.7976931348623157e308);
-          const unsigned long long rowmask = __builtin_amdgcn_ballot_w64((lv >> r) & 1);
-          if (rowmask) {  // (uniform) the row's live groups are g0 .. g1; dead pairs of a live group leave as 0.0
-            const uint32_t g0 = (uint32_t)__builtin_ctzll(rowmask) >> 4, g1 = (63u - (uint32_t)__builtin_clzll(rowmask)) >> 4;
-            const uint32_t base = rowpg[row0 + r];
-            if (grp >= g0 && grp <= g1) dst[(uint64_t)(base + grp - g0) * 64] = c;
-          }
+          // rowpg: the slot group column group 0 of the row would have (its first LIVE group's, minus that group's index)
+          double *drow = dunit + (int64_t)(int32_t)rowpg[row0 + r] * 64;
+          if ((live >> (8 + r)) & 1) drow[loff] = c;
         }
         // a term that is not finite (an all-zero individual: 0/0 in normalize(), as on the CPU): k_spill_sanitize
         // (contract_mfma.hip) then goes over this chunk before it is contracted

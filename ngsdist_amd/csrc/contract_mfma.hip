@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_spill_sanitize(double *__restrict__ C, 
 }
 
 // The job's sums leave D for the caller's [n_mat][n_pairs] arrays in the reference's pair order (ngsDist.cpp:244-245).
-// Pair slot of (row, column) of a tile: 16 * (rowpg[tile * 64 + row] + column / 16 - the row's first live group) + column % 16
+// Pair slot of (row, column) of a tile: 16 * (rowpg[tile * 64 + row] + column / 16) + column % 16
 __global__ __launch_bounds__(256) void k_spill_scatter(const double *__restrict__ D, uint32_t n_pg,
                                                         const ngd_tile *__restrict__ tiles, const uint32_t *__restrict__ rowpg,
                                                         uint64_t n_ind, uint64_t n_pairs, uint32_t n_mat,
@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void k_spill_scatter(const double *__restrict_
   const uint32_t row = slot >> 6, col = slot & 63;
   const uint64_t i = (uint64_t)tiles[tile].ti * 64 + row, j = (uint64_t)tiles[tile].tj * 64 + col;
   if (i >= j || j >= n_ind) return;
-  const uint32_t g0 = tiles[tile].ti == tiles[tile].tj ? (row + 1) >> 4 : 0;  // group of the row's first pair
-  const uint64_t p = ((uint64_t)rowpg[tile * 64 + row] + (col >> 4) - g0) * 16 + (col & 15);
+  const uint64_t p = (uint64_t)(uint32_t)((int32_t)rowpg[tile * 64 + row] + (int32_t)(col >> 4)) * 16 + (col & 15);
   const uint64_t out = ngd_pair_idx(n_ind, i, j);
   for (uint32_t r = 0; r < n_mat; r++)
     d_sum[(uint64_t)r * n_pairs + out] =

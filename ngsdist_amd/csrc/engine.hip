@@ -128,7 +128,8 @@ struct ngd_engine {
   unsigned long long *d_nanflag = nullptr;
   uint64_t cap_D = 0, cap_nanflag = 0;
   // ... its pair slots: groups of 16 consecutive columns of one row of a 64 x 64 tile, dealt to the groups that hold a
-  // pair only; d_rowpg[tile * 64 + row] = slot group of the row's first live group, n_pg_spill = their number (+ padding to 4)
+  // pair only; d_rowpg[tile * 64 + row] + g = slot group of the row's column group g (a signed 32-bit number: the first live
+  // group's slot group minus that group's index), n_pg_spill = their number (+ padding to 4)
   uint32_t *d_rowpg = nullptr;
   uint32_t n_pg_spill = 0, n_pg_live = 0;
   std::vector<hipEvent_t> ev_spill;  // per chunk: before the weights, the EM pass, the sanitiser, the contraction; + one at the end
@@ -607,10 +608,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
           if (i >= g.n_ind || j0 >= g.n_ind) continue;
           const uint64_t first = tiles64[t].ti == tiles64[t].tj ? row + 1 : 0, last = std::min<uint64_t>(63, g.n_ind - 1 - j0);
           if (first > last) continue;
-          rowpg[t * 64 + row] = (uint32_t)n_live;
+          rowpg[t * 64 + row] = (uint32_t)n_live - (uint32_t)(first >> 4);  // (+ a column group's index = its slot group)
           n_live += (last >> 4) - (first >> 4) + 1;
         }
-      if (n_live + 4 < (1ull << 32)) {  // (else: the plan is not offered, em_spill_impl)
+      if (n_live + 4 < (1ull << 31)) {  // (else: the plan is not offered, em_spill_impl)
         e->n_pg_live = (uint32_t)n_live;
         e->n_pg_spill = (uint32_t)((n_live + 3) / 4 * 4);  // a wavefront of the contraction takes 2 or 4 slot groups
         TRY(dev_alloc(e, &e->d_rowpg, rowpg.size(), false));

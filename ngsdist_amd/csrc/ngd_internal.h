@@ -141,8 +141,8 @@ void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const do
                                      uint64_t sites_per_slice, double *slab, unsigned long long *d_counters);
 
 // accum_em_table.hip, terms not summed over the slice: sites [s_lo, s_hi) in units of q consecutive sites (one term per
-// pair slot and unit) into C (fragment-major: k-groups of 4 units x n_pg groups of 16 pair slots; d_rowpg[tile * 64 + row] =
-// slot group of the row's first live group of 16 columns, ngd_spill_slot_groups()); *d_nanflag = 1 if a term was not finite
+// pair slot and unit) into C (fragment-major: k-groups of 4 units x n_pg groups of 16 pair slots; d_rowpg[tile * 64 + row] + g =
+// slot group of the row's group g of 16 columns, for the groups that hold a pair); *d_nanflag = 1 if a term was not finite
 void ngd_launch_accum_em_table_spill(hipStream_t st, const ngd_geom &g, const double *PA, uint64_t s_lo, uint64_t s_hi,
                                      const ngd_score &score, int pairwise_del, const ngd_tile *d_tiles64,
                                      uint32_t n_tiles64, uint32_t n_ks, uint64_t sites_per_slice, uint32_t q,

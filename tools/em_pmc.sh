@@ -1,22 +1,25 @@
 #!/bin/bash
-# tools/em_pmc.sh [kernel] [n_sites] -- VALU issue / lane occupancy / LDS counters of an EM kernel (cfg4 shape)
-#   -> gpurun_out/prof_em_<kernel>/ ; two --pmc passes (8 SQ slots each) + a --kernel-trace --stats pass
+# tools/em_pmc.sh [kernel] [n_sites] [workload] -- VALU issue / lane occupancy / LDS counters of an EM kernel (cfg4 shape;
+# workload emboot: the SPILL instantiation inside the spilled-terms bootstrap job, one launch per chunk of sites)
+#   -> gpurun_out/prof_em_<kernel>[_<workload>]/ ; two --pmc passes (8 SQ slots each) + a --kernel-trace --stats pass
 set -u
 KERNEL=${1:-em_table}
 NS=${2:-100000}
+WL=${3:-cfg4}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_em_$KERNEL
+[ "$WL" = cfg4 ] || OUT=${OUT}_$WL
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload cfg4 --kernel $KERNEL --n_sites $NS --steps 2 --warmup 1 --no_cpu"
+ARGS="--workload $WL --kernel $KERNEL --n_sites $NS --steps 2 --warmup 1 --no_cpu"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
   --output-format csv -d "$OUT/pmc" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc.json" 2> "$OUT/pmc.err"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAVES \
   --output-format csv -d "$OUT/pmc2" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc2.json" 2> "$OUT/pmc2.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/kt.json" 2> "$OUT/kt.err"
-cd "$ROOT" && python3 - "$OUT" "$KERNEL" "$NS" <<'PY'
+cd "$ROOT" && python3 - "$OUT" "$KERNEL" "$NS" "$WL" <<'PY'
 import csv, glob, sys, collections, json
-out, kernel, ns = sys.argv[1], sys.argv[2], float(sys.argv[3])
+out, kernel, ns, wl = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
 d = collections.defaultdict(list)
 for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -24,10 +27,10 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
             d[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in d.items()}
 line = json.loads(open(out + "/kt.json").read().strip().splitlines()[-1])
-ps = 499500 * ns
+ps = 499500 * ns / line["roofline"].get("launches_per_job", 1)  # pair-sites of ONE launch (emboot: a chunk of sites)
 ms = line["roofline"]["ms_per_launch"]
 cyc = m["GRBM_GUI_ACTIVE"] / 8
-print("# rocprofv3 --pmc, EM kernel %s, 1000 x %g sites, one launch = %.4g pair-sites\n" % (kernel, ns, ps))
+print("# rocprofv3 --pmc, EM kernel %s, workload %s, 1000 x %g sites, one launch = %.4g pair-sites\n" % (kernel, wl, ns, ps))
 print("| counter | mean per launch |\n|---|---|")
 for k in sorted(m):
     print("| %s | %.4g |" % (k, m[k]))
@@ -47,10 +50,10 @@ print("- %.3g pair-sites/s" % (ps / (ms * 1e-3)))
 import hashlib, os
 src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
 sha = hashlib.sha256(open(os.path.join("ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
-json.dump({"source": "tools/em_pmc.sh %s %g (rocprofv3 --pmc, two passes)" % (kernel, ns), "kernel_source_sha16": {src: sha},
+json.dump({"source": "tools/em_pmc.sh %s %g %s (rocprofv3 --pmc, two passes)" % (kernel, ns, wl), "kernel_source_sha16": {src: sha},
            "per_pair_site": {"active_lane_instructions": m["SQ_THREAD_CYCLES_VALU"] / ps, "issue_slots": m["SQ_INSTS_VALU"] * 64 / ps,
                              "lds_wave_instructions": m.get("SQ_INSTS_LDS", 0) / ps},
            "lane_occupancy": m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"] / 64,
            "lds_busy": m.get("SQ_LDS_IDX_ACTIVE", 0) / (256 * cyc), "shader_mhz": cyc / ms / 1e3},
-          open(out + "/valu_cfg4_%s.json" % kernel, "w"), indent=1)
+          open(out + "/valu_%s_%s.json" % (wl, kernel), "w"), indent=1)
 PY

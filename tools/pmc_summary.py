@@ -56,6 +56,13 @@ if stats:
                       "roofline.frac recomputed from the trace = %.4f (the line says %.4f)\n"
                       % (k, ms, r["ms_per_launch"], line["ms_per_step"], r["frac"] * r["ms_per_launch"] / ms, r["frac"]))
                 break
+        c = r.get("contract")
+        if c:
+            for k, ms in kt_ms.items():
+                if "k_contract_mfma" in k:
+                    print("`%s`: trace average %.4f ms against %.4f ms per launch by HIP events inside the same run -> its "
+                          "roofline.contract.frac recomputed from the trace = %.4f (the line says %.4f, bound: %s)\n"
+                          % (k, ms, c["ms_per_launch"], c["frac"] * c["ms_per_launch"] / ms, c["frac"], c["bound"]))
 
 print("## --pmc passes (mean per launch; every pass is a separate run)\n")
 print("| pass | kernel | counter | launches | mean per launch |")
@@ -70,16 +77,16 @@ for p in ("fetch", "write", "sq", "l2", "l1"):
             acc[key][0] += float(r["Counter_Value"])
             acc[key][1].add(r["Dispatch_Id"])
         for (k, c), (v, ids) in sorted(acc.items()):
-            if "accum" not in k and "reduce" not in k and "count" not in k:
+            if not any(w in k for w in ("accum", "reduce", "count", "contract", "spill")):
                 continue
             mean = v / max(1, len(ids))
             agg[(k, c)] = mean
             print("| %s | %s | %s | %d | %.6g |" % (p, k, c, len(ids), mean))
 print()
 traffic = {}
-print("## derived (dominant accumulation kernel)\n")
+print("## derived (accumulation kernels; k_contract_mfma of the spilled-terms plan)\n")
 for k in sorted({k for (k, _) in agg}):
-    if "accum" not in k:
+    if "accum" not in k and "contract" not in k:
         continue
     g = lambda c: agg.get((k, c))
     print("kernel `%s`:" % k)
@@ -114,7 +121,8 @@ if traffic:
     import hashlib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src_sha = {}
-    for f in sorted(glob.glob(os.path.join(root, "ngsdist_amd", "csrc", "accum_*.hip"))):
+    for f in sorted(glob.glob(os.path.join(root, "ngsdist_amd", "csrc", "accum_*.hip")) +
+                    glob.glob(os.path.join(root, "ngsdist_amd", "csrc", "contract_mfma.hip"))):
         src_sha[os.path.basename(f)] = hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
     with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump({"source": os.path.basename(out), "kernel_source_sha16": src_sha, "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
