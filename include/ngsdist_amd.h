@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 4 /* 4: ngd_last_spill_timing; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
+#define NGD_ABI_VERSION 4 /* 4: ngd_last_spill_timing, ngd_last_fixup, ngd_image_mode, ngd_config.single_image 0 = auto / 3 = two images; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
@@ -76,19 +76,28 @@ typedef struct ngd_config {
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 / 3 = always issue only the MFMA tiles a     */
                          /* block needs, in blocks of up to 4 x 4 / 2 x 4 tiles of 16 x 16 pairs       */
                          /* (auto: when n_ind padded to 128 is at most 384)                            */
-  uint32_t single_image; /* NGD_KERNEL_MFMA holds two operand images (p and q = score . p, ngsDist.cpp:351-353    */
-                         /* regrouped): 48 bytes per (padded individual, site).  ONE image, i.e. twice the sites   */
-                         /* per engine (1000 x 1e6: 27-30 GB instead of 51):                                       */
-                         /* 2 = in coordinates in which the (symmetric) score matrix is diagonal, score = SUM_r    */
-                         /*     d_r c_r c_r^T: the image holds t_r = c_r . p, both operands are read from it, d    */
-                         /*     rides on the per-index weights.  The speed of two images (46.2 vs 45.6 ms).  The   */
-                         /*     squares differ in sign: sums are exact for called genotypes (c, d dyadic for the   */
-                         /*     reference's matrices) and otherwise carry an ABSOLUTE error of <= 4e-17 per site   */
-                         /*     (1e-9 relative wherever a pair's mean per-site term is above 4e-8; seven digits    */
-                         /*     below the last one printed).  NGD_E_INVALID for an asymmetric score matrix.         */
-                         /* 1 = p resident, q formed for a range of sites at a time before the launch that reads   */
-                         /*     it: the arithmetic of two images (sums equal to rounding, per-block partial sums    */
-                         /*     bit for bit), any score matrix, a fifth more time (55.6 ms)                         */
+  uint32_t single_image; /* NGD_KERNEL_MFMA: how many operand images the engine holds.  Two (p and q = score . p,           */
+                         /* ngsDist.cpp:351-353 regrouped) are 48 bytes per (padded individual, site); ONE is 24, i.e.    */
+                         /* up to twice the sites per engine and half the HBM reads per pass:                              */
+                         /* 2 = ONE image in coordinates in which the (symmetric) score matrix is diagonal, score = SUM_r  */
+                         /*     d_r c_r c_r^T: the image holds t_r = c_r . p, both operands are read from it, d rides on   */
+                         /*     the per-index weights.  The speed of two images.  The squares differ in sign: sums are     */
+                         /*     exact for called genotypes (c, d dyadic for the reference's matrices) and otherwise carry  */
+                         /*     an ABSOLUTE error of <= 4e-17 per site -- 1e-9 relative wherever a pair's mean per-site    */
+                         /*     term is above 4e-8.  For the reference's two matrices (parse_args.cpp:25-27, :134-137) the */
+                         /*     pairs below that -- nearly identical individuals -- are then RECOMPUTED with the two-operand */
+                         /*     arithmetic (the fix-up pass: every pair whose sum is below 1e-6 x the sites visited; it    */
+                         /*     needs min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so   */
+                         /*     1e-9 relative holds at any distance; ngd_last_fixup() reports what a run recomputed, and   */
+                         /*     that nothing was if more than 4096 pairs of a matrix qualified (a data set of clones).     */
+                         /*     Any other symmetric matrix: no fix-up.  NGD_E_INVALID for an asymmetric matrix.            */
+                         /* 1 = p resident, q formed for a range of sites at a time before the launch that reads it: the   */
+                         /*     arithmetic of two images (sums equal to rounding, per-block partial sums bit for bit), any  */
+                         /*     score matrix, a fifth more time (55.6 ms at 1000 x 1e6 instead of 45.6)                    */
+                         /* 3 = two images, always                                                                         */
+                         /* 0 = auto: 2 where its fix-up pass exists (the reference's matrices) and memory matters (more   */
+                         /*     than 384 padded individuals: the block forms below that take no per-index weights in their */
+                         /*     fastest variant), else two images.  ngd_image_mode() tells what an engine holds.           */
   uint32_t second_image_mib; /* single_image = 1: MiB of q kept resident all the same, from the first site on      */
                          /* (what the device has to spare): only the rest is formed range by range, and the extra */
                          /* time shrinks in proportion                                                             */
@@ -270,6 +279,19 @@ int ngd_drop_caches(ngd_engine *e);
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
+/* What the engine holds (ngd_config.single_image resolved): 3 = two operand images, 1 = one image + the second formed a
+ * range at a time, 2 = one image in congruent coordinates; 0 = not an MFMA engine.  *fixup (may be NULL) = 1 if the
+ * engine recomputes the pairs its congruent arithmetic cannot hold to 1e-9 relative (the reference's score matrices). */
+int ngd_image_mode(const ngd_engine *e, int *fixup);
+/* The fix-up pass of the last run call (single_image = 2 engines on the reference's matrices; zeros otherwise): pairs
+ * whose sum in a matrix of the job was below 1e-6 x the sites the matrix visits, how many of them were recomputed with
+ * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more than
+ * 4096 at once: absolute error <= 4e-17 per site), and the device time of the recomputation. */
+typedef struct ngd_fixup_info {
+  uint64_t flagged, recomputed, skipped;
+  double ms;
+} ngd_fixup_info;
+int ngd_last_fixup(const ngd_engine *e, ngd_fixup_info *info);
 /* The accumulation phase of the last run that took the spilled-terms plan (EM path, bootstrap blocks too small for
  * per-block partials: NGD_OPT_EM_SPILL), kernel by kernel, HIP events on the engine's stream summed over the job's chunks
  * of sites -- for roofline accounting (bench.py --workload emboot).  All zero if the last run took another plan. */

@@ -55,13 +55,17 @@ class NgdSpillTiming(C.Structure):
                                   "matrix_groups", "contract_launches")]
 
 
+class NgdFixupInfo(C.Structure):
+    _fields_ = [("flagged", C.c_uint64), ("recomputed", C.c_uint64), ("skipped", C.c_uint64), ("ms", C.c_double)]
+
+
 # every symbol include/ngsdist_amd.h declares (tests/test_abi.py checks the header against this)
 EXPORTS = [
     "ngd_last_error", "ngd_abi_version", "ngd_device_count", "ngd_create", "ngd_destroy",
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
     "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
-    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
+    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_fixup", "ngd_image_mode", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair", "ngd_shard_map",
     "ngd_score_congruence",
 ]
@@ -120,6 +124,9 @@ def load():
     L.ngd_set_option.argtypes = [vp, C.c_int, u64]
     L.ngd_last_timing.argtypes = [vp, C.POINTER(NgdTiming)]
     L.ngd_last_spill_timing.argtypes = [vp, C.POINTER(NgdSpillTiming)]
+    L.ngd_last_fixup.argtypes = [vp, C.POINTER(NgdFixupInfo)]
+    L.ngd_image_mode.argtypes = [vp, C.POINTER(C.c_int)]
+    L.ngd_image_mode.restype = C.c_int
     L.ngd_last_em_work.argtypes = [vp, u64p, u64p]
     L.ngd_last_shader_clock.argtypes = [vp, dp]
     L.ngd_finish.argtypes = [dp, u64p, u64, u64, u64, dp]

@@ -48,6 +48,14 @@ struct ngd_engine {
   bool single_image = false;    // (ngd_config.single_image = 1: q is formed range by range)
   bool congruent = false;       // ngd_config.single_image = 2: the image holds t (sc.c, sc.d), read for both operands
   double *d_wD = nullptr;       // ... and these are the weights of a plain pass: sc.d[k % 3] per contraction index
+  // ... and, for the reference's matrices (sc.fix), the fix-up pass of the pairs its arithmetic cannot hold to 1e-9
+  // relative (fixup.hip): SM[site][individual] = min(p0, p2) beside the image, the pairs a reduction noted, scratch
+  double *SM = nullptr;
+  unsigned long long *d_fixlist = nullptr;
+  uint32_t *d_fixcount = nullptr, *d_fixseen = nullptr, *h_fixcount = nullptr;
+  double *d_fixparts = nullptr, *d_fixthr = nullptr;
+  uint64_t cap_fixthr = 0;
+  ngd_fixup_info fix_info{};
   double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
   uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
@@ -210,7 +218,7 @@ void ngd_destroy(ngd_engine *e) {
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag,
-                  e->d_rowpg};
+                  e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -219,6 +227,7 @@ void ngd_destroy(ngd_engine *e) {
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
   }
   if (e->h_clk) hipHostFree(e->h_clk);
+  if (e->h_fixcount) hipHostFree(e->h_fixcount);
   if (e->d_nan) hipFree(e->d_nan);
   if (e->h_mult) hipHostFree(e->h_mult);
   for (auto &v : e->ev)
@@ -237,7 +246,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // tile lists index groups of 16 individuals with 16 bits; what bounds n_ind in practice is device memory (two
   // n_pairs-long result arrays + one n_pad x n_pad plane per slice), checked below before any list is built
   if ((cfg->n_ind + 127) / 128 * 8 > 65535) return fail(NGD_E_INVALID, "ngd_create: n_ind above 1 048 448 (16-bit tile indices)");
-  if (cfg->single_image > 2) return fail(NGD_E_INVALID, "ngd_create: single_image is 0, 1 or 2");
+  if (cfg->single_image > 3) return fail(NGD_E_INVALID, "ngd_create: single_image is 0 (auto), 1, 2 or 3 (two images)");
   if (cfg->second_image_mib && cfg->single_image != 1)
     return fail(NGD_E_INVALID, "ngd_create: second_image_mib belongs to single_image = 1 engines");
   if (cfg->exact_shapes > 6)
@@ -496,11 +505,26 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } else {
     TRY(dev_alloc(e, &e->PA, frag_elems, true));
     e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image == 1;
-    if (kernel == NGD_KERNEL_MFMA && cfg->single_image == 2) {
-      if (ngd_score_congruence(cfg->score, e->sc.c, e->sc.d) != NGD_OK)
+    if (kernel == NGD_KERNEL_MFMA && (cfg->single_image == 2 || cfg->single_image == 0)) {
+      const bool ok = ngd_score_congruence(cfg->score, e->sc.c, e->sc.d) == NGD_OK;
+      if (!ok && cfg->single_image == 2)
         return bail(fail(NGD_E_INVALID, "ngd_create: single_image = 2 needs a symmetric score matrix (single_image = 1 takes any)"));
-      e->congruent = true;
-      e->sc.congruent = 1;
+      if (ok) {
+        // the reference's two matrices (parse_args.cpp:25-27, :134-137): t = (p0 + p1 + p2, +-(p2 - p0), p1) -- the third
+        // square of --avg_nuc_dist has weight 0 and an empty row, which then carries p1 all the same -- is the form the
+        // fix-up pass recovers p from (fixup.hip)
+        double *c = e->sc.c;
+        if (e->sc.d[2] == 0 && c[6] == 0 && c[7] == 0 && c[8] == 0) c[7] = 1.0;
+        const bool form = c[0] == 1 && c[1] == 1 && c[2] == 1 && c[4] == 0 && (c[3] == 1 || c[3] == -1) && c[5] == -c[3] &&
+                          c[6] == 0 && c[7] == 1 && c[8] == 0;
+        e->sc.fix = form ? 1 : 0;
+        e->sc.fix_sign = c[5];
+      }
+      // auto: one image in congruent coordinates where it is safe (the fix-up pass exists for this matrix) and where memory
+      // matters -- the block forms of a few hundred individuals take no per-index weights in their fastest variant
+      e->congruent = ok && (cfg->single_image == 2 || (e->sc.fix && e->exact_shapes == 0));
+      e->sc.congruent = e->congruent ? 1 : 0;
+      if (!e->congruent) e->sc.fix = 0;
     }
     if (e->single_image) {  // ... and as much of the second image as the caller has memory to spare for
       e->qb_res_kg = std::min<uint64_t>(g.n_kg, ((uint64_t)cfg->second_image_mib << 20) / ((uint64_t)g.n_ig * 64 * 8));
@@ -518,6 +542,16 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (e->congruent) {
     TRY(dev_alloc(e, &e->d_wD, 4 * (g.n_kg + NGD_KG_TAIL), false));
     ngd_launch_index_weights(e->st, 4 * (g.n_kg + NGD_KG_TAIL), e->sc.d, e->d_wD);
+  }
+  if (e->congruent && e->sc.fix) {
+    TRY(dev_alloc(e, &e->SM, g.n_sites * g.n_ind, true));
+    TRY(dev_alloc(e, &e->d_fixlist, NGD_FIX_CAP, false));
+    TRY(dev_alloc(e, &e->d_fixcount, 1, true));
+    TRY(dev_alloc(e, &e->d_fixseen, n_pairs / 32 + 1, true));
+    TRY(dev_alloc(e, &e->d_fixparts, NGD_FIX_CAP, false));
+    if (hipHostMalloc((void **)&e->h_fixcount, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+      return bail(fail(NGD_E_NOMEM, "ngd_create: no pinned host memory for the fix-up count"));
+    *e->h_fixcount = 0;
   }
   TRY(dev_alloc(e, &e->d_sum, n_pairs, true));
   TRY(dev_alloc(e, &e->d_cnt, n_pairs, true));
@@ -654,7 +688,7 @@ static int upload_common(ngd_engine *e, const double *p, int ind_major, uint64_t
       HIPCHK(hipMemcpyAsync(e->staging, p + done * n_ind * 3, c * n_ind * 24, hipMemcpyHostToDevice, e->st));
     }
     ngd_launch_layout(e->st, e->g, e->staging, ind_major, s0 + done, c, e->sc, e->cfg.pairwise_del, e->PA,
-                      e->QB, e->PI, e->mask);
+                      e->QB, e->congruent ? e->SM : e->PI, e->mask);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->st));  // staging buffer is reused by the next chunk
     done += c;
@@ -710,7 +744,8 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
   HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, e->st));
   HIPCHK(hipEventRecord(e->pin_free[b], e->st));
   ngd_launch_prep_layout(e->st, e->g, e->draw[b], s0, n, prep->in_logscale, prep->call_geno, prep->N_thresh,
-                         prep->call_thresh, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask, e->d_nan);
+                         prep->call_thresh, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->congruent ? e->SM : e->PI, e->mask,
+                         e->d_nan);
   HIPCHK(hipGetLastError());
   e->pin_lent = -1;
   e->pin_cur = b ^ 1;
@@ -768,7 +803,8 @@ int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_
   if (!e) return fail(NGD_E_INVALID, "ngd_synth_fill: null engine");
   if (e->committed) return fail(NGD_E_INVALID, "ngd_synth_fill: data set already committed");
   HIPCHK(hipSetDevice(e->device));
-  ngd_launch_synth(e->st, e->g, seed, miss_frac, site0, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->PI, e->mask);
+  ngd_launch_synth(e->st, e->g, seed, miss_frac, site0, e->sc, e->cfg.pairwise_del, e->PA, e->QB,
+                   e->congruent ? e->SM : e->PI, e->mask);
   HIPCHK(hipGetLastError());
   return ngd_commit(e);
 }
@@ -902,6 +938,44 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
   t.launches += launches;
 }
 
+// single_image = 2 engines on the reference's matrices: the pairs the last reduction noted (sums too small for the
+// congruent arithmetic to hold to 1e-9 relative: nearly identical individuals) are recomputed with two-operand arithmetic
+// from p recovered out of the image and the side array (fixup.hip).  The stream is idle and *h_fixcount has arrived.
+//  * a single matrix (d_sum != NULL): over the sites [0, s_hi) with the per-site weights ws (NULL: none), the sums written
+//    over the MFMA pass's;
+//  * per-block partial results (d_sum == NULL): the noted pairs' entries of slab_boot, slice by slice -- the caller then
+//    forms the replicates again.
+// More than NGD_FIX_CAP noted pairs (a data set of clones): nothing is recomputed, ngd_last_fixup() says so.
+static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
+                      uint32_t n_slab_slices, bool *patched) {
+  if (patched) *patched = false;
+  const uint32_t n = *(volatile uint32_t *)e->h_fixcount;
+  e->fix_info.flagged += n;
+  if (!n) return NGD_OK;
+  if (n > NGD_FIX_CAP) { e->fix_info.skipped += n; return NGD_OK; }
+  hipEvent_t t0 = e->ev[0], t1 = e->ev[1];  // (the pass's own timings have been read)
+  HIPCHK(hipEventRecord(t0, e->st));
+  if (d_sum) {
+    uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / n, (s_hi + 1023) / 1024));
+    const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
+    n_slices = (s_hi + sps - 1) / sps;
+    ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixlist, n, 0, s_hi, sps, (uint32_t)n_slices, 0, e->d_fixparts);
+    ngd_launch_fixup_finish(e->st, e->g, e->d_fixlist, n, e->d_fixparts, (uint32_t)n_slices, d_sum);
+  } else {
+    ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixlist, n, 0, s_hi, sites_per_slice, n_slab_slices, 1,
+                     e->slab_boot);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(t1, e->st));
+  HIPCHK(hipStreamSynchronize(e->st));
+  float ms = 0;
+  hipEventElapsedTime(&ms, t0, t1);
+  e->fix_info.ms += ms;
+  e->fix_info.recomputed += n;
+  if (patched) *patched = true;
+  return NGD_OK;
+}
+
 // One accumulation pass over the resident data set: the full data set (mult == NULL) or one bootstrap
 // replicate given as block multiplicities (applied inside the accumulation kernel).
 static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uint64_t n_blocks, uint64_t block_size,
@@ -963,9 +1037,13 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   HIPCHK(hipEventRecord(e->ev[2], e->st));
   // (without --pairwise_del the reduction writes the counts too: every pair visits the same number of sites)
   const bool cnt_in_reduce = e->kernel != NGD_KERNEL_STREAM && !e->cfg.pairwise_del;
+  const bool fix = e->SM != nullptr;  // (a congruent single-image MFMA engine on one of the reference's matrices)
+  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen};
+  if (fix) HIPCHK(hipMemsetAsync(e->d_fixcount, 0, sizeof(uint32_t), e->st));
   if (e->kernel != NGD_KERNEL_STREAM)
     ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, d_sum, cnt_in_reduce ? d_cnt : nullptr,
-                      mult ? n_drawn : n_eff);
+                      mult ? n_drawn : n_eff, fix ? &ff : nullptr, NGD_FIX_MEAN * (double)(mult ? n_drawn : n_eff));
+  if (fix) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
@@ -977,6 +1055,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));
   read_timing(e, n_eff, 1, add_timing);
+  if (fix) return fixup_pass(e, ws, n_eff, d_sum, 0, 0, nullptr);
   return NGD_OK;
 }
 
@@ -1097,7 +1176,21 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     HIPCHK(hipMemsetAsync(d_sum, 0, (uint64_t)n_rep * n_pairs * sizeof(double), e->st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_rep * n_pairs * sizeof(unsigned long long), e->st));
   }
-  ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum);
+  const bool fix = e->SM != nullptr && mfma;  // (see pass_impl)
+  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen};
+  std::vector<double> thr;
+  if (fix) {  // a pair is noted if its sum in ANY matrix is below NGD_FIX_MEAN x the sites that matrix visits
+    thr.resize(n_rep);
+    for (uint32_t r = 0; r < n_rep; r++) thr[r] = NGD_FIX_MEAN * (double)drawn[r];
+    rc = ensure_cap(e, &e->d_fixthr, &e->cap_fixthr, (uint64_t)n_rep);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_fixthr, thr.data(), (uint64_t)n_rep * 8, hipMemcpyHostToDevice, e->st));
+    HIPCHK(hipMemsetAsync(e->d_fixcount, 0, sizeof(uint32_t), e->st));
+    HIPCHK(hipMemsetAsync(e->d_fixseen, 0, (n_pairs / 32 + 1) * sizeof(uint32_t), e->st));
+  }
+  ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum,
+                      fix ? &ff : nullptr, e->d_fixthr);
+  if (fix) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[3], e->st));
 
@@ -1129,6 +1222,16 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));  // W, M, drawn are host temporaries
   read_timing(e, n_eff, launches, false);
+  if (fix) {  // the noted pairs' partial results exactly, then the replicates again from the patched slab
+    bool patched = false;
+    rc = fixup_pass(e, nullptr, n_eff, nullptr, block_size / sub, (uint32_t)n_slices, &patched);
+    if (rc) return rc;
+    if (patched) {
+      ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(e->st));
+    }
+  }
   return NGD_OK;
 }
 
@@ -1372,6 +1475,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   HIPCHK(hipSetDevice(e->device));
   const ngd_geom &g = e->g;
   e->spill_timing = ngd_spill_timing{};
+  e->fix_info = ngd_fixup_info{};
   if (!n_rep) return pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
 
   if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
@@ -1650,6 +1754,19 @@ int ngd_last_shader_clock(const ngd_engine *e, double *mhz) {
   if (!e || !mhz) return fail(NGD_E_INVALID, "ngd_last_shader_clock: null argument");
   *mhz = e->clk_mhz;
   return NGD_OK;
+}
+
+int ngd_last_fixup(const ngd_engine *e, ngd_fixup_info *info) {
+  if (!e || !info) return fail(NGD_E_INVALID, "ngd_last_fixup: null argument");
+  *info = e->fix_info;
+  return NGD_OK;
+}
+
+int ngd_image_mode(const ngd_engine *e, int *fixup) {
+  if (!e) return fail(NGD_E_INVALID, "ngd_image_mode: null engine");
+  if (fixup) *fixup = e->SM != nullptr;
+  if (e->kernel != NGD_KERNEL_MFMA) return 0;
+  return e->congruent ? 2 : e->single_image ? 1 : 3;
 }
 
 int ngd_last_spill_timing(const ngd_engine *e, ngd_spill_timing *t) {

@@ -23,10 +23,12 @@
 //    range of sites and computes all pairs over it; the per-range sums are added -- byte-identical output for called
 //    genotypes, <= 1e-12 relative otherwise), --device D (first device), --same_device (every range on --device: a
 //    rehearsal on one GPU), --max_device_bytes B (device budget; a data set above it goes through in several ranges
-//    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful, --single_image (--indep_geno on the MFMA
-//    kernel: ngd_config.single_image = 2 -- ONE operand image in coordinates in which the score matrix is diagonal: half
-//    the device memory per site, so twice the sites per range, the same speed; called genotypes print the same bytes,
-//    likelihoods agree to 4e-17 per site),
+//    per device), --kernel auto|stream|mfma|em_table|em_fast|em_faithful, --single_image / --two_images (--indep_geno on
+//    the MFMA kernel: ngd_config.single_image = 2 / 3 -- ONE operand image in coordinates in which the score matrix is
+//    diagonal + min(p0, p2) beside it: two thirds of the device memory per site, half the HBM reads, the same speed;
+//    called genotypes print the same bytes, likelihood sums agree to 4e-17 per site and the pairs that is not enough
+//    for, nearly identical individuals, are recomputed the two-operand way -- the engine's own choice above 384
+//    individuals; or both images always),
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
@@ -80,6 +82,7 @@ struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
   bool same_device = false;      // --same_device
   uint64_t max_device_bytes = 0; // --max_device_bytes (0 = 85 % of the device's free memory)
   bool single_image = false;     // --single_image
+  bool two_images = false;       // --two_images
   int prep = 0;  // 0 auto (device unless genotypes are called), 1 host, 2 device
 };
 
@@ -128,6 +131,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
                                  {"same_device", no_argument, nullptr, 1005},
                                  {"max_device_bytes", required_argument, nullptr, 1006},
                                  {"single_image", no_argument, nullptr, 1007},
+                                 {"two_images", no_argument, nullptr, 1008},
                                  {"device", required_argument, nullptr, 1002},
                                  {"kernel", required_argument, nullptr, 1003},
                                  {"prep", required_argument, nullptr, 1004},
@@ -163,6 +167,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
       case 1005: p.same_device = true; break;
       case 1006: p.max_device_bytes = strtoull(optarg, nullptr, 10); break;
       case 1007: p.single_image = true; break;
+      case 1008: p.two_images = true; break;
       case 1002: p.device = atoi(optarg); break;
       case 1003:
         if (!strcmp(optarg, "auto")) p.kernel = NGD_KERNEL_AUTO;
@@ -971,7 +976,8 @@ int main(int argc, char **argv) {
     cfg.indep_geno = p.indep_geno;
     cfg.device = p.same_device ? p.device : p.device + dev_index;
     cfg.kernel = p.kernel;
-    cfg.single_image = p.single_image ? 2 : 0;  // (the MFMA kernel on one operand image; nothing to the other kernels)
+    // (the MFMA kernel on one operand image, on two, or -- 0 -- as the engine chooses; nothing to the other kernels)
+    cfg.single_image = p.single_image ? 2 : p.two_images ? 3 : 0;
     int rc = ngd_create(&cfg, &eng.h);
     if (rc) die_engine("ngd_create", rc);
   };
@@ -984,7 +990,11 @@ int main(int argc, char **argv) {
   // the per-range (sum, cnt) are added.
   const uint64_t n_pad = (p.n_ind + 127) / 128 * 128;
   const bool mfma_path = p.indep_geno && p.kernel != NGD_KERNEL_STREAM;
-  const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind : (mfma_path && !p.single_image ? 48 : 24) * n_pad) +
+  // (one image + the fix-up pass's side array, 24 n_pad + 8 n_ind: --single_image, or the engine's own choice above 384
+  // padded individuals -- ngd_config.single_image = 0; this program's score matrices are the reference's two)
+  const bool one_image = mfma_path && !p.two_images && (p.single_image || n_pad > 384);
+  const uint64_t per_site = (p.kernel == NGD_KERNEL_STREAM ? 24 * p.n_ind
+                             : one_image ? 24 * n_pad + 8 * p.n_ind : (mfma_path ? 48 : 24) * n_pad) +
                             (p.pairwise_del ? p.n_ind / 8 + 1 : 0) + 40;
   const uint64_t n_t = n_pad / 128, n_slabs = std::max<uint64_t>(8, std::min<uint64_t>(256, 8192 / (n_t * (n_t + 1) / 2)));
   const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);

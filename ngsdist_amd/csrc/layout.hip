@@ -16,13 +16,16 @@ inline ngd_d3 d3_of(const double *d3) { return d3 ? ngd_d3{{d3[0], d3[1], d3[2]}
 __device__ __forceinline__ void emit(const ngd_geom &g, const ngd_score &sc, int pairwise_del,
                                      uint64_t s, uint32_t i, double p0, double p1, double p2,
                                      double *PA, double *QB, double *PI, unsigned long long *mask) {
-  if (PI) {  // individual-major copy for the streaming kernel (unmasked, as gen_dist reads it)
+  if (PI && !sc.congruent) {  // individual-major copy for the streaming kernel (unmasked, as gen_dist reads it)
     double *d = PI + (i * g.n_sites_pad + s) * 3;
     d[0] = p0; d[1] = p1; d[2] = p2;
   }
   bool miss = ngd_miss(p0, p1, p2);
   if (mask && !miss) atomicOr(&mask[(uint64_t)i * g.n_words + (s >> 6)], 1ull << (s & 63));
   if (pairwise_del && miss) { p0 = 0; p1 = 0; p2 = 0; }  // a skipped site contributes nothing
+  // congruent image of the reference's matrices, t = (p0 + p1 + p2, +-(p2 - p0), p1): the smaller of p0 and p2 is what
+  // the image cannot hold to the last bit -- kept beside it (site-major: coalesced here), p is then recoverable (fixup.hip)
+  if (PI && sc.congruent) PI[s * g.n_ind + i] = p0 < p2 ? p0 : p2;
   uint64_t k = 3 * s;
   if (PA && sc.congruent) {  // t_r = c_r . p (products and sums rounded one by one; exact for called genotypes)
     for (int r = 0; r < 3; r++) {

@@ -20,6 +20,12 @@ struct ngd_score {
   // per-index weights.  congruent = 0: the image holds p.
   double c[9], d[3];
   int congruent;
+  // congruent images of the reference's two matrices (parse_args.cpp:25-27, :134-137) hold t = (p0 + p1 + p2, +-(p2 - p0),
+  // p1): with min(p0, p2) kept beside the image (one double per individual and site), p comes back to the last bit or
+  // so -- what the fix-up pass of nearly identical pairs recomputes from (fixup.hip).  fix = 1: the image has that form
+  // (fix_sign = the sign of p2 in t_1); 0: any other symmetric matrix, no fix-up.
+  int fix;
+  double fix_sign;
 };
 
 // Geometry of the resident data set.
@@ -73,6 +79,8 @@ struct ngd_job {
 
 // ---- kernel launchers (each in its own .hip file) -------------------------
 // layout.hip
+// (PI: the individual-major copy of the streaming kernel -- or, with score.congruent and score.fix, the side array
+// SM[site][individual] = min(p0, p2) of the fix-up pass)
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,
                        uint64_t s0, uint64_t n_sites_chunk, const ngd_score &score, int pairwise_del,
                        double *PA, double *QB, double *PI, unsigned long long *mask);
@@ -170,17 +178,39 @@ void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *
                                const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,
                                uint64_t sites_per_slice, double *slab);
 
+// fixup.hip : single_image = 2 engines, the pairs whose sums the congruent arithmetic cannot hold to 1e-9 relative
+// (mean per-site term below NGD_FIX_MEAN: nearly identical individuals) recomputed with two-operand arithmetic from
+// p recovered out of the image T and the side array SM[site][individual] = min(p0, p2).
+#define NGD_FIX_MEAN 1e-6  // flag a pair whose sum is below this x the sites its matrix visits (error bound: 4e-17 per site)
+#define NGD_FIX_CAP 4096u  // pairs recomputed per pass at most; beyond that the sums stay as they are (ngd_last_fixup)
+struct ngd_fix_flags {     // what the reduction kernels need to note the pairs that want the fix-up
+  unsigned long long *list;  // [NGD_FIX_CAP] (i << 32) | j
+  uint32_t *count;           // pairs noted (may exceed the capacity: then the fix-up is skipped)
+  uint32_t *seen;            // [n_pairs / 32 + 1] one bit per pair, for reductions that visit a pair once per replicate chunk
+};
+// out_mode 0: the partial sum of pair slot q over slice sl goes to out[q * n_slices + sl]; 1: to the slab entry
+// out[(sl * n_pad + i) * n_pad + j] (per-block partial results).  Slice sl = sites [s_lo + sl * sites_per_slice, ...) below s_hi.
+void ngd_launch_fixup(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,
+                      const uint32_t *d_ws, const unsigned long long *d_list, uint32_t n_list, uint64_t s_lo, uint64_t s_hi,
+                      uint64_t sites_per_slice, uint32_t n_slices, int out_mode, double *out);
+// out_mode 0's second step: d_sum[pair] = the pair's slices added in ascending order
+void ngd_launch_fixup_finish(hipStream_t st, const ngd_geom &g, const unsigned long long *d_list, uint32_t n_list,
+                             const double *parts, uint32_t n_slices, double *d_sum);
+
 // reduce.hip : deterministic slab reduction + valid-site counting
 // planes_per_slice: the slab holds that many result planes per slice (EM batch kernel), `slab` points at
 // the first slice's plane of the wanted result
 // d_cnt != NULL: every pair's count is set to cnt_value in the same launch (no --pairwise_del)
+// fix != NULL (single_image = 2 engines): pairs whose sum is below fix_thr are noted for the fix-up pass
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
                        uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
-                       unsigned long long *d_cnt = nullptr, unsigned long long cnt_value = 0);
+                       unsigned long long *d_cnt = nullptr, unsigned long long cnt_value = 0,
+                       const ngd_fix_flags *fix = nullptr, double fix_thr = 0);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
+// fix != NULL: a pair is noted if its sum in ANY replicate r is below d_thr[r]
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         double *d_sum);
+                         double *d_sum, const ngd_fix_flags *fix = nullptr, const double *d_thr = nullptr);
 void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
                          uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
                          unsigned long long *d_cnt);

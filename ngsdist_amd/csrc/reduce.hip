@@ -23,7 +23,8 @@ __device__ __forceinline__ bool ngd_finite(double v) { return __builtin_fabs(v) 
 __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab, uint32_t n_ks,
                                                  uint32_t planes_per_slice, const ngd_tile *__restrict__ tiles,
                                                  uint32_t n_pad, uint64_t n_ind, double *__restrict__ d_sum,
-                                                 unsigned long long *__restrict__ d_cnt, unsigned long long cnt_value) {
+                                                 unsigned long long *__restrict__ d_cnt, unsigned long long cnt_value,
+                                                 ngd_fix_flags fix, double fix_thr) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
@@ -38,8 +39,15 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
   }
   for (int u = 0; ks < n_ks; ks++, u++) s[u] += p[(uint64_t)ks * plane];
   const uint64_t idx = ngd_pair_idx(n_ind, i, j);
-  d_sum[idx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  const double sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  d_sum[idx] = sum;
   if (d_cnt) d_cnt[idx] = cnt_value;
+  // single_image = 2 engines: a sum this small is not held to 1e-9 relative by the congruent arithmetic -- noted for the
+  // fix-up pass (fixup.hip); rare, so one atomic per noted pair
+  if (fix.list && sum < fix_thr) {
+    const uint32_t slot = atomicAdd(fix.count, 1u);
+    if (slot < NGD_FIX_CAP) fix.list[slot] = ((unsigned long long)i << 32) | j;
+  }
 }
 
 // Bootstrap replicates from per-block partial sums, RB replicates per pass over the slab:
@@ -54,7 +62,8 @@ __global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ sl
                                                     const double *__restrict__ W, uint32_t w_stride,
                                                     uint32_t n_rep, const ngd_tile *__restrict__ tiles,
                                                     uint32_t n_pad, uint64_t n_ind, uint64_t n_pairs,
-                                                    double *__restrict__ d_sum) {
+                                                    double *__restrict__ d_sum, ngd_fix_flags fix,
+                                                    const double *__restrict__ fix_thr) {
   const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
   const uint32_t i = tiles[tile].ti * NGD_TILE + row;
   const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
@@ -106,9 +115,18 @@ __global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ sl
     }
   }
   const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+  bool small = false;
 #pragma unroll
   for (int r = 0; r < RB; r++)
-    if (r0 + r < n_rep) d_sum[(uint64_t)(r0 + r) * n_pairs + idx] = acc[r];
+    if (r0 + r < n_rep) {
+      d_sum[(uint64_t)(r0 + r) * n_pairs + idx] = acc[r];
+      if (fix.list) small = small || acc[r] < fix_thr[r0 + r];
+    }
+  // single_image = 2 engines (see k_reduce): noted once, whichever replicate chunk sees a small sum first
+  if (small && !((atomicOr(&fix.seen[idx >> 5], 1u << (idx & 31)) >> (idx & 31)) & 1u)) {
+    const uint32_t slot = atomicAdd(fix.count, 1u);
+    if (slot < NGD_FIX_CAP) fix.list[slot] = ((unsigned long long)i << 32) | j;
+  }
 }
 
 // The same for the valid-site counts of --pairwise_del: cnt[r][pair] = SUM_b M[b][r] * C[b][pair] with
@@ -271,9 +289,10 @@ __global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long *
 
 template <int RB>
 void reduce_wb(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
-               uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum) {
+               uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
+               const ngd_fix_flags &fix, const double *d_thr) {
   hipLaunchKernelGGL((k_reduce_wb<RB>), dim3(n_tiles * NGD_TILE, (n_rep + RB - 1) / RB), dim3(128), 0, st, slab,
-                     n_ks, d_W, w_stride, n_rep, d_tiles, g.n_pad, g.n_ind, g.n_ind * (g.n_ind - 1) / 2, d_sum);
+                     n_ks, d_W, w_stride, n_rep, d_tiles, g.n_pad, g.n_ind, g.n_ind * (g.n_ind - 1) / 2, d_sum, fix, d_thr);
 }
 
 template <int RB>
@@ -288,10 +307,10 @@ void reduce_cb(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_
 
 void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks,
                        uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
-                       unsigned long long *d_cnt, unsigned long long cnt_value) {
+                       unsigned long long *d_cnt, unsigned long long cnt_value, const ngd_fix_flags *fix, double fix_thr) {
   if (!n_tiles) return;
   hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, planes_per_slice, d_tiles,
-                     g.n_pad, g.n_ind, d_sum, d_cnt, cnt_value);
+                     g.n_pad, g.n_ind, d_sum, d_cnt, cnt_value, fix ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr}, fix_thr);
 }
 
 // replicates per pass over the partials; the weight arrays are padded to a multiple of it
@@ -299,13 +318,14 @@ uint32_t ngd_reduce_chunk(uint32_t n_rep) { return n_rep <= 1 ? 1 : n_rep <= 4 ?
 
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         double *d_sum) {
+                         double *d_sum, const ngd_fix_flags *fix, const double *d_thr) {
   if (!n_tiles || !n_rep) return;
+  const ngd_fix_flags f = fix && d_thr ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr};
   switch (ngd_reduce_chunk(n_rep)) {
-    case 1: reduce_wb<1>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
-    case 4: reduce_wb<4>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
-    case 16: reduce_wb<16>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum); break;
-    default: reduce_wb<32>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum);
+    case 1: reduce_wb<1>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
+    case 4: reduce_wb<4>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
+    case 16: reduce_wb<16>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
+    default: reduce_wb<32>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr);
   }
 }
 

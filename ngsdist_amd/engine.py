@@ -53,7 +53,7 @@ class Engine:
 
     def __init__(self, n_ind, n_sites, score=None, pairwise_del=False, indep_geno=True, kernel="auto",
                  device=-1, shard_rank=0, shard_world=1, variant=0, n_slices=0, wg_target=0, exact_shapes=0,
-                 single_image=False, second_image_bytes=0):
+                 single_image=0, second_image_bytes=0):
         self._L = _lib.load()
         self._h = C.c_void_p()
         cfg = _lib.NgdConfig()
@@ -66,7 +66,8 @@ class Engine:
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
         # launch geometry, 0 = the engine's defaults (ngd_config)
         cfg.variant, cfg.n_slices, cfg.wg_target, cfg.exact_shapes = int(variant), int(n_slices), int(wg_target), int(exact_shapes)
-        # MFMA kernel: one resident operand image -- 1 / True: the other formed per launch, 2: congruent coordinates
+        # MFMA kernel, operand images: 0 = the engine's choice, 1 / True: one + the other formed per launch, 2: one in
+        # congruent coordinates (+ the fix-up pass of nearly identical pairs), 3: two
         cfg.single_image = int(single_image)
         cfg.second_image_mib = int(second_image_bytes) >> 20  # ... except this much of it, kept resident all the same
         self.n_ind, self.n_sites = int(n_ind), int(n_sites)
@@ -238,6 +239,18 @@ class Engine:
         """the spilled-terms plan's accumulation phase kernel by kernel (ngd_last_spill_timing); zeros after another plan"""
         t = _lib.NgdSpillTiming()
         _check(self._L.ngd_last_spill_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def image_mode(self):
+        """(what the engine holds: 3 two images / 1 / 2, 0 = not an MFMA engine; whether it recomputes nearly identical pairs)"""
+        f = C.c_int(0)
+        m = self._L.ngd_image_mode(self._h, C.byref(f))
+        return int(m), bool(f.value)
+
+    def fixup(self):
+        """the fix-up pass of the last run (ngd_last_fixup): flagged / recomputed / skipped pairs, ms"""
+        t = _lib.NgdFixupInfo()
+        _check(self._L.ngd_last_fixup(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
     def em_work(self):

@@ -34,8 +34,9 @@ def test_cfg2_every_pair_against_the_oracle():
 
 @pytest.fixture(scope="module")
 def cfg3_mfma():
-    """configs[2]: n_ind=1000, n_sites=1e6, GL, --indep_geno (51 GB resident)"""
-    e = N().Engine(1000, 1_000_000, kernel="mfma")
+    """configs[2]: n_ind=1000, n_sites=1e6, GL, --indep_geno, both operand images (51 GB resident; the engine's own choice
+    at this size is ONE image + the fix-up pass: test_cfg3_single_image_engine)"""
+    e = N().Engine(1000, 1_000_000, kernel="mfma", single_image=3)
     e.synth_fill(3)
     yield e
     e.close()
@@ -94,8 +95,9 @@ def test_cfg3_streaming_kernel_agrees_on_every_pair(cfg3_mfma):
 
 def test_cfg3_single_image_engine(cfg3_mfma):
     """ngd_config.single_image at full size.  1: 30 GB resident instead of 51 (p only; q = score . p formed a range of
-    sites at a time), the whole pass equal to rounding, per-block partial sums bit for bit.  2: 27 GB (one image in
-    coordinates in which the score matrix is diagonal), everything equal to rounding."""
+    sites at a time), the whole pass equal to rounding, per-block partial sums bit for bit.  2 (the engine's own choice at
+    this size): 35 GB (one image in coordinates in which the score matrix is diagonal + min(p0, p2) beside it for the
+    fix-up pass of nearly identical pairs -- none in this data set), everything equal to rounding."""
     full, cnt = cfg3_mfma.run()
     perm = np.random.default_rng(0).permutation(np.arange(1000, dtype=np.uint64))
     cfg3_mfma.set_option("boot_partials", 2)
@@ -115,11 +117,14 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         e.set_option("boot_partials", 0)
         sw, _ = e.run(perm, 1000)
         assert rel(sw, s_perm) < 1e-12
-    # single_image = 2, the one image in congruent coordinates: 27 GB, sums to 1e-12, partial sums too
-    with N().Engine(1000, 1_000_000, kernel="mfma", single_image=2) as e:
+    # single_image = 2, the one image in congruent coordinates (what single_image = 0 picks here): 35 GB, sums to 1e-12,
+    # partial sums too
+    with N().Engine(1000, 1_000_000, kernel="mfma") as e:
+        assert e.image_mode() == (2, True)
         e.synth_fill(3)
-        assert e.device_bytes() < 28e9
+        assert e.device_bytes() < 36e9
         s, c = e.run()
+        assert e.fixup() == {"flagged": 0, "recomputed": 0, "skipped": 0, "ms": 0.0}
         assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
         assert np.array_equal(e.run()[0], s)
         e.set_option("boot_partials", 2)

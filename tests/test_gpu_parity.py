@@ -497,10 +497,10 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes, resident):
     pc = np.zeros((n_ind, n_sites, 3))
     np.put_along_axis(pc, rng.integers(0, 3, size=(n_ind, n_sites))[..., None], 1.0, axis=2)
     out = []
-    for single in (False, True):
+    for single in (3, 1):  # two images / p resident, q formed a range at a time
         with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single,
-                        second_image_bytes=resident if single else 0) as e:
-            if single and scratch_bytes:
+                        second_image_bytes=resident if single == 1 else 0) as e:
+            if single == 1 and scratch_bytes:
                 e.set_option("single_image_bytes", scratch_bytes)
             e.upload_ind_major(p).commit()
             r = [e.run()]
@@ -511,8 +511,8 @@ def test_mfma_single_image_engine(n_ind, form, scratch_bytes, resident):
             r.append(e.run())
             nbytes = e.device_bytes()
         with N().Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form, single_image=single,
-                        second_image_bytes=resident if single else 0) as e:
-            if single and scratch_bytes:
+                        second_image_bytes=resident if single == 1 else 0) as e:
+            if single == 1 and scratch_bytes:
                 e.set_option("single_image_bytes", scratch_bytes)
             e.upload_ind_major(pc).commit()
             e.set_option("boot_partials", 0)
@@ -549,7 +549,7 @@ def test_mfma_congruent_single_image_engine(n_ind, form, avg_nuc_dist):
     pc = np.zeros((n_ind, n_sites, 3))
     np.put_along_axis(pc, rng.integers(0, 3, size=(n_ind, n_sites))[..., None], 1.0, axis=2)
     out = []
-    for single in (0, 2):
+    for single in (3, 2):
         with N().Engine(n_ind, n_sites, score=score, pairwise_del=True, kernel="mfma", exact_shapes=form, single_image=single) as e:
             e.upload_ind_major(p).commit()
             r = [e.run()]
@@ -577,30 +577,107 @@ def test_mfma_congruent_single_image_engine(n_ind, form, avg_nuc_dist):
         assert np.array_equal(one[k][1], cb) and rel_err(one[k][0], sb) < RTOL, k
 
 
-def test_congruent_single_image_accuracy_on_nearly_identical_individuals():
-    """what single_image = 2 gives up: the three squares carry different signs, so a pair's sum is a difference of terms
-    of order 1 per site and its ABSOLUTE error is that of those terms -- a few 1e-17 per site (here, on copies of one
-    individual, of one sign: it adds up linearly) -- relative to the sum only as long as the per-site terms are not tiny.
-    Copies of one individual with likelihoods confident to 1e-9: per-site terms of 4e-9, sums of 2e-5.  The two-image
-    engine holds 1e-9 relative there (all terms positive); the one-image engine holds 4e-17 per site (measured 1.7e-17),
-    i.e. 4e-9 of these sums -- and 1e-9 relative wherever a pair's mean per-site term is above 4e-8 (ordinary distances,
-    test above: 1e-13).  In the printed matrix (%.10f of sum / n_sites) 4e-17 per site is seven digits below the last."""
-    n_ind, n_sites = 32, 5000
-    rng = np.random.default_rng(5)
-    g = rng.integers(0, 3, size=n_sites)
-    eps = 1e-9 * (1 + rng.random((n_ind, n_sites, 3)))
-    p = eps.copy()
+def clones(n_ind, n_sites, eps, seed=5, n_free=0, hom_only=False):
+    """copies of one individual whose likelihoods are confident to `eps` (per-site terms of ~4 eps between two of them);
+    the last n_free individuals are ordinary ones.  hom_only: no heterozygous sites (under --avg_nuc_dist two copies of a
+    heterozygote are half a difference apart, parse_args.cpp:134-137)"""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 2, size=n_sites) * 2 if hom_only else rng.integers(0, 3, size=n_sites)
+    p = eps * (1 + rng.random((n_ind, n_sites, 3)))
     p[:, np.arange(n_sites), g] = 0
     p[:, np.arange(n_sites), g] = 1 - p.sum(axis=2)
-    so, co = O.all_pairs(p, n_threads=8)
-    assert so.max() < 1e-4
-    with N().Engine(n_ind, n_sites, kernel="mfma") as e:
+    if n_free:
+        p[n_ind - n_free:] = O.synth_indmajor(seed, n_free, n_sites)
+    return p
+
+
+@pytest.mark.parametrize("avg_nuc_dist", [False, True])
+@pytest.mark.parametrize("eps", [1e-9, 1e-13, 1e-22])
+def test_congruent_single_image_recomputes_nearly_identical_pairs(avg_nuc_dist, eps):
+    """single_image = 2: the three squares carry different signs, so a pair's sum is a difference of terms of order 1 per
+    site and its ABSOLUTE error is a few 1e-17 per site -- not enough for copies of one individual with likelihoods
+    confident to 1e-9 and less (per-site terms of 4e-9 ... 4e-22), which two images hold to 1e-9 relative.  For the
+    reference's matrices the engine therefore recomputes every pair whose sum is below 1e-6 x the sites visited with the
+    two-operand arithmetic of ngsDist.cpp:351-353, from p recovered out of the image and min(p0, p2) kept beside it
+    (fixup.hip): 1e-9 relative at ANY distance -- a plain pass, a weighted pass, per-block partial sums (aligned and
+    masked slices; one and several replicates), --pairwise_del with missing sites -- and only those pairs: the others
+    keep the bits of the one-image pass."""
+    n_ind, n_sites, n_free = 40, 5000, 8
+    score = O.score_matrix(avg_nuc_dist)
+    p = clones(n_ind, n_sites, eps, n_free=n_free, hom_only=avg_nuc_dist)
+    p[3, 100:140] = 1.0 / 3  # missing sites of one clone (--pairwise_del skips them)
+    n_clone_pairs = N().n_pairs(n_ind - n_free)
+    so, co = O.all_pairs(p, score=score, pairwise_del=True, n_threads=8)
+    assert np.sort(so)[n_clone_pairs - 1] < 1e-4 * (eps / 1e-9) and np.sort(so)[n_clone_pairs] > 100
+    with N().Engine(n_ind, n_sites, score=score, pairwise_del=True, kernel="mfma", single_image=2) as e:
+        assert e.image_mode() == (2, True)
+        e.upload_ind_major(p).commit()
+        s1, c1 = e.run()
+        f = e.fixup()
+        assert f["flagged"] == f["recomputed"] == n_clone_pairs and f["skipped"] == 0
+        assert np.array_equal(c1, co) and rel_err(s1, so) < RTOL
+        for B, partials, n_rep in ((8, 2, 1), (6, 2, 1), (7, 0, 1), (8, 2, 5), (5, 2, 40)):
+            e.set_option("boot_partials", partials)
+            maps = np.stack([N().Taus(B + r).block_map(n_sites // B) for r in range(n_rep)])
+            S, Cn = e.run_batch(maps, B)
+            assert e.fixup()["recomputed"] >= n_clone_pairs
+            for r in sorted({0, n_rep - 1}):
+                sb, cb = O.all_pairs(p, score=score, pairwise_del=True, site_src=O.boot_site_src(maps[r], B),
+                                     n_sites=n_sites // B * B, n_threads=8)
+                assert np.array_equal(Cn[r], cb) and rel_err(S[r], sb) < RTOL, (B, partials, n_rep, r)
+        S, Cn = e.run_job(np.stack([N().Taus(3).block_map(n_sites // 4)]), 4)  # the whole loop: full data + a replicate
+        assert rel_err(S[0], so) < RTOL
+    # the same engine without the recomputation would be off by up to 4e-17 per site: a general symmetric matrix gets none
+    with N().Engine(n_ind, n_sites, score=score, pairwise_del=True, kernel="mfma", single_image=3) as e:
         s2, _ = e.upload_ind_major(p).commit().run()
+        assert e.image_mode() == (3, False) and e.fixup()["flagged"] == 0
+    assert rel_err(s2, so) < RTOL
+    big = so > 100  # pairs with an ordinary individual: not recomputed
+    assert rel_err(s1[big], s2[big]) < 1e-12
+
+
+def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
+    """more pairs than the fix-up pass takes at once (4096): nothing is recomputed, the sums keep the one-image
+    arithmetic's absolute bound of 4e-17 per site (seven digits below the last one %.10f prints), and ngd_last_fixup()
+    says so; a symmetric matrix that is not one of the reference's has no fix-up pass at all"""
+    n_ind, n_sites = 100, 3000
+    p = clones(n_ind, n_sites, 1e-9)
+    so, co = O.all_pairs(p, n_threads=8)
     with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
         s1, c1 = e.upload_ind_major(p).commit().run()
-    assert np.array_equal(c1, co) and rel_err(s2, so) < RTOL
-    assert np.max(np.abs(s1 - so)) < 4e-17 * n_sites
+        f = e.fixup()
+    assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
+    assert np.array_equal(c1, co) and np.max(np.abs(s1 - so)) < 4e-17 * n_sites
     assert np.array_equal(np.round(s1 / n_sites, 10), np.round(so / n_sites, 10))
+    score = np.array([[0, 0.25, 1], [0.25, 0, 0.5], [1, 0.5, 0.125]])
+    with N().Engine(32, n_sites, score=score, kernel="mfma", single_image=2) as e:
+        assert e.image_mode() == (2, False)
+        s, c = e.upload_ind_major(p[:32]).commit().run()
+        assert e.fixup()["flagged"] == 0
+    so, co = O.all_pairs(p[:32], score=score, n_threads=8)
+    assert np.array_equal(c, co) and rel_err(s, so) < RTOL  # (score[2][2] > 0: copies are not close under this matrix)
+    with N().Engine(32, n_sites, score=score, kernel="mfma") as e:  # auto: two images for such a matrix
+        assert e.image_mode() == (3, False)
+
+
+def test_auto_holds_one_image_where_memory_matters():
+    """ngd_config.single_image = 0: one image in congruent coordinates + the fix-up pass above 384 padded individuals (the
+    reference's matrices), two images below (the block forms of a few hundred individuals) and for other matrices"""
+    for n_ind, want in ((385, (2, True)), (384, (3, False)), (50, (3, False))):
+        with N().Engine(n_ind, 256, kernel="mfma") as e:
+            assert e.image_mode() == want, n_ind
+    with N().Engine(500, 256, kernel="mfma", score=O.score_matrix(True)) as e:
+        assert e.image_mode() == (2, True)
+    with N().Engine(500, 256, kernel="mfma", single_image=3) as e:
+        assert e.image_mode() == (3, False)
+    with N().Engine(500, 256, kernel="stream") as e:
+        assert e.image_mode() == (0, False)
+    p = clones(500, 2000, 1e-10, n_free=470)
+    so, co = O.all_pairs(p, n_threads=8)
+    with N().Engine(500, 2000, kernel="mfma") as e:
+        s, c = e.upload_ind_major(p).commit().run()
+        assert e.fixup()["recomputed"] == N().n_pairs(30)
+    assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
 def test_congruent_single_image_needs_a_symmetric_score_matrix():

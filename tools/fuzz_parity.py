@@ -38,6 +38,8 @@ for case in range(first, first + n_cases):
     rng_si = np.random.default_rng(7_000_000 + case)
     single = kernel == "mfma" and bool(rng_si.integers(0, 2))  # ngd_config.single_image; the scratch: 4 GB or the smallest ranges
     single_bytes = int(rng_si.choice([0, 1, 1 << 20])) if single else 0
+    if kernel == "mfma" and not single:
+        geom["single_image"] = int(rng_si.choice([0, 3]))  # the engine's choice / two images always
     if single:
         geom["single_image"] = int(rng_si.integers(1, 3))  # 1: the second image formed in ranges; 2: congruent coordinates
         if geom["single_image"] == 1:
