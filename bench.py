@@ -128,8 +128,9 @@ def main():
     ap.add_argument("--n_boot", type=int, default=-1, help="override the workload's --n_boot_rep (bootstrap workloads)")
     ap.add_argument("--block", type=int, default=0, help="override the workload's --boot_block_size (bootstrap workloads)")
     ap.add_argument("--single_image", type=int, nargs="?", const=1, default=0,
-                    help="ngd_config.single_image: hold one operand image -- 1: the other formed a range of sites at a time "
-                         "(memory for time), 2: both operands from one image in congruent coordinates")
+                    help="ngd_config.single_image: 0 = the engine's choice (one image in congruent coordinates + the fix-up pass "
+                         "above 384 padded individuals), 1: one image, the other formed a range of sites at a time (memory for "
+                         "time), 2: both operands from one image in congruent coordinates, 3: two images")
     ap.add_argument("--single_image_gb", type=float, default=0.0,
                     help="with --single_image: GB of the second image formed at a time (NGD_OPT_SINGLE_IMAGE_BYTES; 0 = 4)")
     ap.add_argument("--second_image_gb", type=float, default=0.0,
@@ -159,6 +160,9 @@ def main():
     ap.add_argument("--pipelined_tail", action="store_true",
                     help="run the second (pipelined) region also where it is skipped by default: jobs of under 1e5 cells, "
                          "and N > 1 (collectives on the worker thread: rehearsed over gloo only)")
+    ap.add_argument("--poll_sclk", action="store_true",
+                    help="poll pp_dpm_sclk from a thread during the timed region (off by default: it shares the interpreter "
+                         "with the timed loop; the clock reported is the one sampled inside the kernel, shader_clock_mhz)")
     ap.add_argument("--vary_jobs", action="store_true",
                     help="test path: odd steps compute another job than even steps (a bootstrap replicate instead of the "
                          "full-data matrix / the replicates in reverse order), every tail records a checksum of its whole "
@@ -260,6 +264,9 @@ def main():
         eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
     for name, v in W.get("options", {}).items():
         eng.set_option(name, v)
+    # what the engine holds: 3 = both operand images, 2 = ONE in congruent coordinates (+ the fix-up pass of nearly identical
+    # pairs when `fixup`), 1 = one + the other formed a range at a time; 0 = not the MFMA kernel
+    image_mode, has_fixup = eng.image_mode()
 
     torch.set_num_threads(1)  # no CPU tensor math here; keep OpenMP's spinning workers out of the way
 
@@ -598,7 +605,7 @@ def main():
     fence()
     import threading
     poller = threading.Thread(target=poll_clock, daemon=True)
-    if rank == 0:
+    if rank == 0 and args.poll_sclk:
         poller.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -716,7 +723,7 @@ def main():
                 "traffic": None, "ms_per_launch": acc_mean_ms,
                 "algorithmic": "%.0f FP64 flop per pair-site x %.4g pair-sites per launch"
                                % (FLOPS_PER_PAIR_SITE, pair_sites_per_launch_all / world)}
-        if args.single_image == 1:
+        if image_mode == 1:
             roof["note"] = ("single-image engine: a pass is one launch of the kernel per range of the second operand image "
                             "plus the kernel that forms the range (k_qb_range, HBM-bound); ms_per_launch is the whole "
                             "accumulation phase of a pass, frac the pass's flops against it")
@@ -825,7 +832,7 @@ def main():
     # measured on is the one this library was built from (sha256 recorded by tools/pmc_summary.py)
     try:
         import hashlib
-        tname = "traffic_%s_%s.json" % (args.workload, "single_image%d" % args.single_image if args.single_image else kernel)
+        tname = "traffic_%s_%s.json" % (args.workload, "single_image%d" % image_mode if image_mode in (1, 2) else kernel)
         tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         src = "accum_%s.hip" % {"em_fast": "em", "em_faithful": "em", "em_table": "em_table"}.get(kernel, kernel)
         now = hashlib.sha256(open(os.path.join(ROOT, "ngsdist_amd", "csrc", src), "rb").read()).hexdigest()[:16]
@@ -863,6 +870,7 @@ def main():
                          "source": "%s (the level marked current), polled every 2 ms during the timed region; on some boxes "
                                    "this file reports an idle level throughout -- shader_clock_mhz is the figure to use" % clk["src"]}
                         if clk["mhz"] else None)
+    roof["sclk_poller_active_during_value"] = bool(args.poll_sclk)
     pipeline_check = None
     if args.vary_jobs:
         a, b = sums_seen["serial"][-args.steps:], sums_seen["pipelined"][-args.steps:]
@@ -882,7 +890,12 @@ def main():
                                + (" --pairwise_del (%.3g of the sites missing; not a BASELINE configuration)" % args.miss_frac
                                   if pdel else ""),
                    "kernel": kernel, "matrices_per_step": n_mat, "n_pairs": n_pairs,
-                   "device_bytes": eng.device_bytes(), "single_image": args.single_image, "second_image_gb": args.second_image_gb if args.single_image == 1 else None,
+                   "device_bytes": eng.device_bytes(), "single_image": args.single_image,
+                   "image_mode": {"resolved": image_mode, "fixup_pass": has_fixup, "last_fixup": eng.fixup(),
+                                  "meaning": "3 = two operand images, 2 = one image in congruent coordinates (fixup_pass: pairs "
+                                             "below 1e-6 per site are recomputed the two-operand way), 1 = one image + the other "
+                                             "formed a range at a time, 0 = not the MFMA kernel"},
+                   "second_image_gb": args.second_image_gb if args.single_image == 1 else None,
                    "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
                                "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
                                "device buffers, copied to pinned host memory"),

@@ -73,9 +73,16 @@ typedef struct ngd_config {
   uint32_t n_slices;     /* slices of the site axis per launch (MFMA: rounded up to a multiple of 8);  */
                          /* held to what the data set allows (>= 128 k-groups / >= 1 site per slice)  */
   uint32_t wg_target;    /* workgroups wanted per launch, from which n_slices is derived when it is 0 */
-  uint32_t exact_shapes; /* NGD_KERNEL_MFMA: 1 = never, 2 / 3 = always issue only the MFMA tiles a     */
-                         /* block needs, in blocks of up to 4 x 4 / 2 x 4 tiles of 16 x 16 pairs       */
-                         /* (auto: when n_ind padded to 128 is at most 384)                            */
+  uint32_t exact_shapes; /* NGD_KERNEL_MFMA, block form: issue only the MFMA tiles a block of pairs needs (narrow edge    */
+                         /* blocks, triangular diagonal blocks).  0 = auto: off above 384 padded individuals, else up to  */
+                         /* 208 individuals form 6, up to 256 form 4, else form 2.  1 = never (full 4 x 4 pattern);       */
+                         /* 2 = blocks of up to 4 x 4 tiles of 16 x 16 pairs, one single-wavefront workgroup per block;   */
+                         /* 3 = the same with blocks of up to 2 x 4; 4 / 5 = 2 / 3 with a slice's blocks in ONE workgroup */
+                         /* that moves through the sites in step (<= 12 / <= 16 blocks; a prefetching wavefront where one */
+                         /* fits); 6 = 5 with the operands staged through LDS.  Fallbacks, all silent and result-         */
+                         /* neutral: 4 -> 2 and 5 / 6 -> 3 where a slice's blocks do not fit one workgroup; 6 -> 5 for    */
+                         /* any pass that carries per-index weights -- bootstrap passes, masked partial-sum slices and    */
+                         /* EVERY pass of a single_image = 2 engine (its plain pass is weighted by the congruence)        */
   uint32_t single_image; /* NGD_KERNEL_MFMA: how many operand images the engine holds.  Two (p and q = score . p,           */
                          /* ngsDist.cpp:351-353 regrouped) are 48 bytes per (padded individual, site); ONE is 24, i.e.    */
                          /* up to twice the sites per engine and half the HBM reads per pass:                              */
@@ -276,6 +283,9 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_SINGLE_IMAGE_BYTES 8 /* [0 = 4 GB] ngd_config.single_image engines: bytes of the second operand image */
                                  /*     formed at a time (a pass is so many launches; never less than 64 k-groups per */
                                  /*     slice, or eight bootstrap blocks of a partial-sum pass); set before the first run */
+#define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
+                                 /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
+                                 /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);

@@ -464,6 +464,10 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
   typedef integral_constant<int, 3> I3;
   typedef integral_constant<int, 4> I4;
 
+  // A block shape this form has no code path for (engine.hip builds none: ngd_create checks its job list against
+  // ngd_mfma_shape_listed()): the block's sums leave as NaN and clk[2] tells the host, which fails the run with NGD_E_HIP
+  // -- never a silent matrix of zeros.
+  bool unlisted = false;
   if (kg0 < kg1) {
     if constexpr (EXACT == 0) {
       run(I4{}, I4{}, std::false_type{});
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         case 2 | 3 << 3 | 1 << 6: run_lds(I2{}, I3{}, std::true_type{}); break;
         case 2 | 2 << 3 | 1 << 6: run_lds(I2{}, I2{}, std::true_type{}); break;
         case 1 | 1 << 3 | 1 << 6: run_lds(I1{}, I1{}, std::true_type{}); break;
-        default: break;
+        default: unlisted = true;
       }
     } else {  // EXACT 2 / 4: blocks of at most 2 x 4 tiles (engine.hip builds no other shapes for them), DEPTH k-groups in flight
       typedef integral_constant<int, DEPTH> ID;
@@ -505,11 +509,18 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         case 2 | 3 << 3 | 1 << 6: run_exact(I2{}, I3{}, std::true_type{}, ID{}); break;
         case 2 | 2 << 3 | 1 << 6: run_exact(I2{}, I2{}, std::true_type{}, ID{}); break;
         case 1 | 1 << 3 | 1 << 6: run_exact(I1{}, I1{}, std::true_type{}, ID{}); break;
-        default: break;
+        default: unlisted = true;
       }
     }
   }
 
+  if (unlisted) {  // (uniform)
+#pragma unroll
+    for (int m = 0; m < WM; m++)
+#pragma unroll
+      for (int n = 0; n < WN; n++) acc[m][n] = (ngd_d4){__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+    if (clk && lane == 0) clk[2] = 1ull;
+  }
   if (clk_wave) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {

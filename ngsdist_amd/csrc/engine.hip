@@ -130,7 +130,9 @@ struct ngd_engine {
   // plan options (ngd_set_option)
   uint64_t opt_boot_partials = 1, opt_boot_max_bytes = 0, opt_boot_wg = 4096, opt_boot_unaligned = 1, opt_em_batch = 1;
   uint64_t opt_em_spill = 1, opt_em_spill_bytes = 0;
-  bool em_batch_nofit = false;  // the EM batch pass's result planes did not fit this device: not tried again
+  // the EM batch pass's result planes did not fit this device at this many elements: a request as large is not tried
+  // again (0: nothing has failed) -- until ngd_drop_caches(), or until a smaller request (fewer matrices per pass) comes
+  uint64_t em_batch_nofit_elems = 0;
   // EM bootstrap by spilled terms + one MFMA contraction (contract_mfma.hip): running sums and per-chunk NaN flags
   double *d_D = nullptr;
   unsigned long long *d_nanflag = nullptr;
@@ -447,6 +449,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
           if (d < bin[b].size()) jobs.push_back(bin[b][d]);
     }
   }
+  for (const ngd_job &j : jobs)  // every block must have a code path in the kernel's form (accum_mfma.hip)
+    if (!ngd_mfma_shape_listed(e->exact_shapes, j.rows, j.cols, j.tri))
+      return bail(fail(NGD_E_HIP, "ngd_create: internal -- a block shape the MFMA kernel's form does not list"));
   const uint32_t jobs_per_wg = e->exact_shapes >= 3 ? (uint32_t)jobs.size() : e->exact_shapes ? 1 : 4;
   e->wg_waves = jobs_per_wg;
   while (jobs.size() % jobs_per_wg) jobs.push_back({0, 0, 0, 0, 0, 0});
@@ -604,10 +609,11 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
-    if (hipHostMalloc((void **)&e->h_clk, 2 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+    // ([0..1] the clock sample; [2] set by a block whose shape the kernel does not list: mfma_fault())
+    if (hipHostMalloc((void **)&e->h_clk, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&e->d_clk, e->h_clk, 0) != hipSuccess)
       return bail(fail(NGD_E_NOMEM, "ngd_create: no pinned host memory for the clock sample"));
-    e->h_clk[0] = e->h_clk[1] = 0;
+    e->h_clk[0] = e->h_clk[1] = e->h_clk[2] = e->h_clk[3] = 0;
     if (e->single_image) {
       // scratch for QB: one range of a whole pass (launch_accumulate(); partial-sum passes grow it if a bootstrap
       // block is longer)
@@ -893,6 +899,11 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
                                   e->n_wg, e->exact_shapes, e->wg_waves, n_ks, piece, hi - lo, 0, 0, slab, e->d_clk, 0,
                                   r > 0 || res > 0);
           else {  // (the kernel indexes the image by absolute k-group: an address below the scratch, formed as an integer)
+            // ... so every k-group a launched slice can touch -- its own [kg0, kg1) and the NGD_KG_TAIL k-groups its operand
+            // pipeline (the prefetching wavefront included) runs ahead -- must lie inside the scratch as just formed
+            const uint64_t first = slice_kg0(ks0), last = std::max(first, slice_kg1(ks0 + n - 1));
+            if ((first < lo && first < kg_lim) || last > hi || (hi - lo + NGD_KG_TAIL) * kstride > e->qb_chunk_elems)
+              return fail(NGD_E_HIP, "launch_accumulate: internal -- a slice of the range reaches outside the scratch of the second image");
             const double *moved_back = reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(e->qb_chunk) - lo * kstride * sizeof(double));
             ngd_launch_accum_mfma(e->st, g, e->PA, moved_back, wsel, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n,
                                   per_slice, kg_lim, k_per_slice, w_stride, slab, e->d_clk, ks0);
@@ -910,6 +921,13 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
                           e->kernel == NGD_KERNEL_EM_FAST, e->d_tiles16, e->n_tiles16, n_ks, per_slice, slab);
   }
   return NGD_OK;
+}
+
+// The MFMA kernel met a block whose shape it has no code path for (its sums are NaN): the run fails, loudly.
+static int mfma_fault(ngd_engine *e) {
+  if (!e->h_clk || !((volatile unsigned long long *)e->h_clk)[2]) return NGD_OK;
+  e->h_clk[2] = 0;
+  return fail(NGD_E_HIP, "accum_mfma: a block shape the kernel does not list (its sums were set to NaN)");
 }
 
 static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool add) {
@@ -1055,6 +1073,7 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));
   read_timing(e, n_eff, 1, add_timing);
+  if (int rc = mfma_fault(e)) return rc;
   if (fix) return fixup_pass(e, ws, n_eff, d_sum, 0, 0, nullptr);
   return NGD_OK;
 }
@@ -1222,6 +1241,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
   HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));  // W, M, drawn are host temporaries
   read_timing(e, n_eff, launches, false);
+  if ((rc = mfma_fault(e))) return rc;
   if (fix) {  // the noted pairs' partial results exactly, then the replicates again from the patched slab
     bool patched = false;
     rc = fixup_pass(e, nullptr, n_eff, nullptr, block_size / sub, (uint32_t)n_slices, &patched);
@@ -1275,7 +1295,11 @@ static int em_batch_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
     const uint32_t nq = nr - (lead ? 1u : 0u);                     // replicates in the chunk
     if (e->opt_boot_max_bytes && (uint64_t)b_ks * rb * plane * 8 > e->opt_boot_max_bytes)  // the caller's scratch budget
       return fail(NGD_E_NOMEM, "EM batch pass: result planes exceed NGD_OPT_BOOT_MAX_BYTES");
-    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, (uint64_t)b_ks * rb * plane);
+    const uint64_t want = (uint64_t)b_ks * rb * plane;
+    if (e->em_batch_nofit_elems && want >= e->em_batch_nofit_elems && want > e->slab_boot_elems)
+      return fail(NGD_E_NOMEM, "EM batch pass: result planes of this size did not fit the device before");
+    int rc = ensure_cap(e, &e->slab_boot, &e->slab_boot_elems, want);
+    if (rc == NGD_E_NOMEM && !e->opt_boot_max_bytes) e->em_batch_nofit_elems = want;  // the device's verdict: remembered
     if (rc) return rc;
     rc = ensure_cap(e, &e->d_W, &e->cap_W, g.n_sites * (uint64_t)rb);
     if (rc) return rc;
@@ -1476,6 +1500,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   const ngd_geom &g = e->g;
   e->spill_timing = ngd_spill_timing{};
   e->fix_info = ngd_fixup_info{};
+  e->n_batch_valid = 0;  // (the matrices of an earlier batch are not this call's: set again by copy_out() on success)
   if (!n_rep) return pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
 
   if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
@@ -1559,7 +1584,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   const bool em_pair = e->kernel == NGD_KERNEL_EM_FAST || e->kernel == NGD_KERNEL_EM_FAITHFUL;
   const bool em_table_batch = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape == 0 && n_rep + lead >= 3;
   const bool em_borrow = e->kernel == NGD_KERNEL_EM_TABLE && e->em_shape != 0 && n_rep >= 3;
-  if ((em_pair || em_borrow || em_table_batch) && n_rep + lead >= 2 && e->opt_em_batch && !e->em_batch_nofit) {
+  if ((em_pair || em_borrow || em_table_batch) && n_rep + lead >= 2 && e->opt_em_batch) {
     const bool fold = lead && e->kernel != NGD_KERNEL_EM_FAITHFUL;
     if (lead && !fold) {
       rc = pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
@@ -1572,7 +1597,6 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
     if (rc != NGD_E_NOMEM) return rc;
     (void)hipGetLastError();
     g_err.clear();  // not an error of this call: the matrices are computed one pass each instead
-    if (!e->opt_boot_max_bytes) e->em_batch_nofit = true;  // the device's verdict (not a caller's budget): remembered
     if (lead && !fold) {  // matrix 0 is done already
       for (uint32_t r = 0; r < n_rep; r++) {
         rc = pass_impl(e, mult + (uint64_t)r * n_blocks, mult_max[lead + r], n_blocks, block_size, drawn[lead + r],
@@ -1605,6 +1629,7 @@ static int copy_out(ngd_engine *e, uint32_t n_mat, const double *d_sum, const un
 }
 
 static int batch_buffers(ngd_engine *e, uint32_t n_rep) {
+  e->n_batch_valid = 0;  // (the buffers may be freed and grown below; a failed call leaves nothing to fetch)
   HIPCHK(hipSetDevice(e->device));
   const uint64_t need = (uint64_t)n_rep * ngd_n_pairs(e->g.n_ind);
   if (need <= e->cap_batch) return NGD_OK;
@@ -1729,6 +1754,15 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       if (!e->single_image) break;  // (another kernel, or second_image_mib holds the whole second image: nothing is formed)
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
       break;
+    case NGD_OPT_DEBUG_FORGE_JOB: {  // tests only: the first block of the MFMA job list gets another shape
+      if (e->kernel != NGD_KERNEL_MFMA || !e->d_jobs) return fail(NGD_E_INVALID, "ngd_set_option: no MFMA job list");
+      HIPCHK(hipSetDevice(e->device));
+      ngd_job j;
+      HIPCHK(hipMemcpy(&j, e->d_jobs, sizeof(j), hipMemcpyDeviceToHost));
+      j.rows = (uint8_t)(value & 7); j.cols = (uint8_t)((value >> 3) & 7); j.tri = (uint8_t)((value >> 6) & 1);
+      HIPCHK(hipMemcpy(e->d_jobs, &j, sizeof(j), hipMemcpyHostToDevice));
+      break;
+    }
     default: return fail(NGD_E_INVALID, "ngd_set_option: unknown option");
   }
   return NGD_OK;
@@ -1740,6 +1774,7 @@ int ngd_drop_caches(ngd_engine *e) {
   e->boot_blocks = 0;
   e->cnt_B = 0;
   e->cnt_blocks = 0;
+  e->em_batch_nofit_elems = 0;  // (what did not fit may fit now: the partial results' slab is the same scratch)
   return NGD_OK;
 }
 

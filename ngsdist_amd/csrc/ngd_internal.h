@@ -77,6 +77,16 @@ struct ngd_job {
   uint8_t rows, cols, tri, pad;
 };
 
+// The block shapes accum_mfma.hip has a code path for, per block form (ngd_engine::exact_shapes: 0 full 4 x 4 pattern;
+// 1 / 3 blocks of up to 4 x 4 tiles, any shape falls back to the full pattern; 2 / 4 / 5 blocks of up to 2 x 4).
+// ngd_create() checks the job list it built against this; the kernel poisons (NaN) a block whose shape it does not list.
+inline bool ngd_mfma_shape_listed(int form, uint32_t rows, uint32_t cols, uint32_t tri) {
+  if (rows == 0) return true;  // padding entry
+  if (form == 0 || form == 1 || form == 3) return rows <= 4 && cols <= 4;
+  if (tri) return (rows == 2 && cols >= 2 && cols <= 4) || (rows == 1 && cols == 1);
+  return rows == 2 && cols >= 1 && cols <= 4;
+}
+
 // ---- kernel launchers (each in its own .hip file) -------------------------
 // layout.hip
 // (PI: the individual-major copy of the streaming kernel -- or, with score.congruent and score.fix, the side array

@@ -151,3 +151,49 @@ def test_engines_give_their_device_memory_back():
                 e.commit()  # "NaN found!"
     leaked = base - free_now()
     assert leaked < (64 << 20), "device memory not returned: %d MiB" % (leaked >> 20)
+
+
+def test_nothing_to_fetch_after_a_failed_job():
+    """ngd_fetch_matrix serves the matrices of the LAST batch / job call only: a call that fails (here: a block map entry
+    out of range, found before anything is launched; then a batch whose buffers cannot be allocated) leaves nothing to
+    fetch -- not the matrices of the call before it, whose buffers may have been freed and grown meanwhile"""
+    import ngsdist_amd as N
+    n_ind, n_sites, B = 40, 600, 4
+    p = O.synth_indmajor(3, n_ind, n_sites)
+    maps = np.stack([N.Taus(r).block_map(n_sites // B) for r in range(3)])
+    with N.Engine(n_ind, n_sites, kernel="mfma") as e:
+        e.upload_ind_major(p).commit()
+        assert e.run_job_keep(maps, B) == 4
+        e.fetch_matrix(3)
+        bad = maps.copy()
+        bad[1, 5] = n_sites  # >= n_blocks
+        with pytest.raises(N.NgdError):
+            e.run_job_keep(bad, B)
+        for which in (0, 3):
+            with pytest.raises(N.NgdError):
+                e.fetch_matrix(which)
+        assert e.run_job_keep(maps, B) == 4  # and the engine goes on
+        s, c = e.fetch_matrix(1)
+        s1, c1 = e.run(maps[0], B)
+        assert np.array_equal(c, c1) and np.max(np.abs(s - s1) / s1) < 1e-12
+
+
+@pytest.mark.parametrize("form,shape", [(3, 2 | 1 << 3 | 1 << 6), (5, 1 | 2 << 3), (6, 3 | 3 << 3), (6, 2 | 1 << 3 | 1 << 6)])
+def test_a_block_shape_the_kernel_does_not_list_fails_the_run(form, shape):
+    """accum_mfma.hip has one code path per block shape of a form (rows x cols tiles, triangular or not); ngd_create()
+    builds only listed shapes (and checks).  Should an unlisted one ever reach the kernel -- forged here through the
+    test-only option NGD_OPT_DEBUG_FORGE_JOB -- the block's sums are poisoned and the run fails with NGD_E_HIP, on the
+    plain pass and on the per-block partial sums alike; it used to fall through a `default: break` and return zeros."""
+    import ngsdist_amd as N
+    n_ind, n_sites = 100, 2000
+    p = O.synth_indmajor(8, n_ind, n_sites)
+    with N.Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form) as e:
+        e.upload_ind_major(p).commit()
+        s, c = e.run()
+        e.set_option("debug_forge_job", shape)
+        with pytest.raises(N.NgdError) as ei:
+            e.run()
+        assert ei.value.code == -3  # NGD_E_HIP
+        e.set_option("boot_partials", 2)
+        with pytest.raises(N.NgdError):
+            e.run(N.Taus(1).block_map(n_sites // 8), 8)
