@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--no_preflight", action="store_true",
+                    help="N > 1: skip tools/rccl_preflight.py (the job's collectives timed once before the engine is created)")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicates", "sites", "pairs"],
                     help="N>1: split the site axis (each rank holds 1/N of the data, all pairs; sums are added), or deal "
                          "pair tiles over ranks (input replicated; disjoint results) -- both time the SAME job at every "
@@ -244,6 +246,13 @@ def main():
 
     # bootstrap geometry of the WHOLE data set
     n_mat = W["n_boot"] + 1
+    if world > 1 and not args.no_preflight:
+        # The job's collectives at their real sizes, timed BEFORE the engine exists (tools/rccl_preflight.py): no multi-GPU
+        # node was available to this build, so the first hardware run prints what its reduce-scatter / all-gather cost on
+        # the node it found, beside the RCCL version -- one "rccl_preflight {...}" line on rank 0's stderr
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from rccl_preflight import preflight
+        preflight(dist, dev, args.backend, n_mat * n_pairs, n_pairs if by_reps else 0, repeats=3)
     n_eff = n_sites - n_sites % W["block"]
     if by_sites:
         # contiguous site ranges, whole bootstrap blocks and whole 16-site groups per rank
