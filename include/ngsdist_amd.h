@@ -76,6 +76,10 @@ typedef struct ngd_config {
   uint32_t exact_shapes; /* NGD_KERNEL_MFMA, block form: issue only the MFMA tiles a block of pairs needs (narrow edge    */
                          /* blocks, triangular diagonal blocks).  0 = auto: off above 384 padded individuals, else up to  */
                          /* 208 individuals form 6, up to 256 form 4, else form 2.  1 = never (full 4 x 4 pattern);       */
+                         /* 7 = the full pattern, four blocks to a workgroup, except that the blocks ON the diagonal leave */
+                         /* out the six tiles below it and sit in workgroups of their own (a one-image engine fetches     */
+                         /* their four operand fragments once for rows and columns).  Fewer MFMAs, no faster: such blocks */
+                         /* run ahead of their slice and its operands then leave HBM more than once; */
                          /* 2 = blocks of up to 4 x 4 tiles of 16 x 16 pairs, one single-wavefront workgroup per block;   */
                          /* 3 = the same with blocks of up to 2 x 4; 4 / 5 = 2 / 3 with a slice's blocks in ONE workgroup */
                          /* that moves through the sites in step (<= 12 / <= 16 blocks; a prefetching wavefront where one */

@@ -222,18 +222,46 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
   // two instantiations must not share a control-flow join while loads are in flight: the asm loads
   // are invisible to the compiler, so a register copy it placed at such a join would read a
   // register the load has not written yet.
-  auto run = [&](auto rows_c, auto cols_c, auto tri_c) {
+  // same_c (a block ON the diagonal of an engine whose two operands are ONE image: single_image = 2, PA == QB and
+  // ig0 == jg0): the block's row fragments ARE its column fragments -- four loads per k-group instead of eight, the row
+  // operand is the column operand times the index weight.
+  auto run = [&](auto rows_c, auto cols_c, auto tri_c, auto same_c) {
     constexpr int PM = decltype(rows_c)::value, PN = decltype(cols_c)::value;
-    constexpr bool TRI = decltype(tri_c)::value;
+    constexpr bool TRI = decltype(tri_c)::value, SAME = decltype(same_c)::value;
+    static_assert(!SAME || (DEPTH == 1 && PM == PN), "shared operands: the one-deep form (its wait is vmcnt(0)), square blocks");
+    auto fetch_r = [&](int d, uint64_t kg) {
+      if constexpr (SAME) {
+        const double *xb = pb + kg * kstride;
+        asm volatile(
+            "global_load_dwordx2 %0, %4, %5\n\t"
+            "global_load_dwordx2 %1, %4, %5 offset:512\n\t"
+            "global_load_dwordx2 %2, %4, %5 offset:1024\n\t"
+            "global_load_dwordx2 %3, %4, %5 offset:1536"
+            : "=&v"(bq[d][0]), "=&v"(bq[d][1]), "=&v"(bq[d][2]), "=&v"(bq[d][3])
+            : "v"(lane_off), "s"(xb));
+        if (WEIGHTED) {
+          const double *xw = wk_s + (kg - wk_kg0) * 4;
+          asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(wq[d]) : "v"(lane_wk), "s"(xw));
+        }
+      } else {
+        fetch(d, kg);
+      }
+    };
     uint64_t nxt[DEPTH];  // the k-group the next refill of buffer d fetches
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) fetch(d, kidx(kg0 + d));
+    for (int d = 0; d < DEPTH; d++) fetch_r(d, kidx(kg0 + d));
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) nxt[d] = kidx(kg0 + d + DEPTH);
     for (uint64_t kg = kg0; kg < kg1; kg += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; d++) {
-        arrive(d);
+        if constexpr (SAME) {  // (DEPTH == 1: everything outstanding is this fetch)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq[d][0]), "+v"(bq[d][1]), "+v"(bq[d][2]), "+v"(bq[d][3]), "+v"(wq[d]));
+#pragma unroll
+          for (int m = 0; m < WM; m++) a[d][m] = bq[d][m];
+        } else {
+          arrive(d);
+        }
         if (DEPTH == 1 || kg + d < kg1) {  // a slice need not be a whole number of ring trips
           if (WEIGHTED) {  // bootstrap multiplicity of the site (ngsDist.cpp:426-434)
             const double w = wq[d];
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[d][m], bq[d][n], acc[m][n], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the refill BEHIND the MFMAs that read the buffer
-        fetch(d, nxt[d]);
+        fetch_r(d, nxt[d]);
         __builtin_amdgcn_sched_barrier(0);
         nxt[d] = kidx(kg + d + 2 * DEPTH);
       }
@@ -470,11 +498,20 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
   bool unlisted = false;
   if (kg0 < kg1) {
     if constexpr (EXACT == 0) {
-      run(I4{}, I4{}, std::false_type{});
+      // tri: a block on the diagonal whose lower triangle is left out (ngd_config.exact_shapes = 7: 10 tiles of 16;
+      // engine.hip packs such blocks into workgroups of their own, so that a workgroup's four jobs advance at one rate).
+      // NOT the default: such a block runs through its slice 1.6 times as fast as the others, away from the k-groups
+      // they hold in L2 -- [measured] cfg 5: the fabric delivers 20.1 GB a launch instead of 7.1 (L2 hit rate 0.42 for
+      // 0.76), the clock falls 2.5 % and the pass is no shorter for its 8 % fewer MFMAs; holding the triangular blocks
+      // back (a progress word per slice, naps) made the FULL blocks drift instead: 28 GB, and 217 GB for 39 at cfg 3
+      // (profiles/r05_tri_diag_ab.txt).  Equal work per k-group is what keeps a slice's jobs together.
+      if (!job.tri) run(I4{}, I4{}, std::false_type{}, std::false_type{});
+      else if (DEPTH == 1 && PA == QB && ig0 == jg0) run(I4{}, I4{}, std::true_type{}, integral_constant<bool, DEPTH == 1>{});
+      else run(I4{}, I4{}, std::true_type{}, std::false_type{});
     } else if constexpr (EXACT == 1 || EXACT == 3) {
       switch (shape) {  // rows | cols << 3 | tri << 6
         case 4 | 4 << 3:
-          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{});
+          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{}, std::false_type{});
           break;
         case 4 | 3 << 3: run_exact(I4{}, I3{}, std::false_type{}, I1{}); break;
         case 4 | 2 << 3: run_exact(I4{}, I2{}, std::false_type{}, I1{}); break;
@@ -484,7 +521,7 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         case 2 | 2 << 3 | 1 << 6: run_exact(I2{}, I2{}, std::true_type{}, I1{}); break;
         case 1 | 1 << 3 | 1 << 6: run_exact(I1{}, I1{}, std::true_type{}, I1{}); break;
         default:  // any other shape: the full pattern is always right
-          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{});
+          if constexpr (SYNC) run_exact(I4{}, I4{}, std::false_type{}, I1{}); else run(I4{}, I4{}, std::false_type{}, std::false_type{});
       }
     } else if constexpr (EXACT == 5) {
       switch (shape) {
@@ -537,6 +574,7 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         if (EXACT && (m >= (int)(shape & 7) || n >= (int)((shape >> 3) & 7) || ((shape >> 6) && m > n))) continue;  // (uniform)
+        if (!EXACT && (shape >> 6) && m > n) continue;  // (form 6: a diagonal block's lower triangle was not computed)
         const uint32_t i = (ig0 + m) * 16 + (lane >> 4) + 4 * r;
         const uint32_t j = (jg0 + n) * 16 + (lane & 15);
         // (resume: single-image engines walk a pass in ranges of k-groups, every slice a piece of each range -- the

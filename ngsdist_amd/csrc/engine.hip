@@ -86,6 +86,7 @@ struct ngd_engine {
   uint32_t n_wg = 0;
   uint32_t wg_waves = 4;  // wavefronts (jobs) per workgroup of the MFMA kernel
   int exact_shapes = 0;  // small n_ind: one code path per block shape (accum_mfma.hip EXACT): 1 = blocks of 4 x 4 tiles, 2 = 2 x 4
+  bool tri_diag = false;  // full 4 x 4 blocks (exact_shapes == 0) whose DIAGONAL blocks leave their lower triangle out
   uint64_t *d_pairs = nullptr;
   uint64_t n_owned_pairs = 0;
   // scratch + results
@@ -251,10 +252,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   if (cfg->single_image > 3) return fail(NGD_E_INVALID, "ngd_create: single_image is 0 (auto), 1, 2 or 3 (two images)");
   if (cfg->second_image_mib && cfg->single_image != 1)
     return fail(NGD_E_INVALID, "ngd_create: second_image_mib belongs to single_image = 1 engines");
-  if (cfg->exact_shapes > 6)
+  if (cfg->exact_shapes > 7)
     return fail(NGD_E_INVALID, "ngd_create: exact_shapes must be 0 (auto), 1 (never), 2 (blocks of 4 x 4 tiles), 3 (2 x 4), 4 "
-                               "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup) or 6 (5 with operands "
-                               "through LDS)");
+                               "(4 x 4, a slice's jobs in one workgroup), 5 (2 x 4, one workgroup), 6 (5 with operands "
+                               "through LDS) or 7 (full blocks, triangular on the diagonal)");
   if (cfg->variant > 4) return fail(NGD_E_INVALID, "ngd_create: no such kernel variant");
   const uint32_t world = cfg->shard_world ? cfg->shard_world : 1;
   if (cfg->shard_rank >= world) return fail(NGD_E_INVALID, "ngd_create: shard_rank >= shard_world");
@@ -362,8 +363,12 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   // blocks of 2 x 4 tiles with the operands staged through LDS, up to 16 groups as 10 blocks of 4 x 4 ([measured]
   // 100 000 sites, ms per matrix, plain / in step: n_ind = 100: 0.143 / 0.108; 200: 0.356 / 0.262; 250: 0.427 / 0.387;
   // the forms fall back where a slice's jobs do not fit one workgroup)
-  e->exact_shapes = cfg->exact_shapes ? (cfg->exact_shapes == 1 ? 0 : (int)cfg->exact_shapes - 1)
+  e->exact_shapes = cfg->exact_shapes ? (cfg->exact_shapes == 1 || cfg->exact_shapes == 7 ? 0 : (int)cfg->exact_shapes - 1)
                                       : (g.n_pad > 384 ? 0 : n_igv <= 13 ? 5 : n_igv <= 16 ? 3 : 1);
+  // Above 384 padded individuals every block runs the full 4 x 4 pattern (form 0).  ngd_config.exact_shapes = 7: the
+  // blocks ON the diagonal leave out the 6 tiles below it (10 of 16; on a one-image engine their row fragments are their
+  // column fragments: 4 loads per k-group instead of 8) -- measured, not the default (see accum_mfma.hip).
+  e->tri_diag = cfg->exact_shapes == 7;
   if (e->exact_shapes == 2 || e->exact_shapes >= 4) {
     // strips of two row groups, cut into blocks of four column groups from the diagonal on (the first block of a strip
     // is triangular: 7 tiles of 8); an odd last row is its diagonal tile.  Under pair-tile sharding blocks must not
@@ -399,8 +404,10 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } else {
     // Off-diagonal 128-tile -> its four 64x64 blocks in one workgroup (they share operands); the blocks of
     // the diagonal tiles (two on the diagonal, one above it) follow, packed four to a workgroup.  Every
-    // block runs the full 4x4 pattern, so all workgroups of a slice progress at one rate.
-    std::vector<ngd_job> diag;
+    // block runs the full 4x4 pattern, so all workgroups of a slice progress at one rate --
+    // tri_diag: the blocks ON the diagonal are triangular (10 tiles of 16) and come last, in workgroups of their
+    // own, so that the four jobs of a workgroup still move through the sites together.
+    std::vector<ngd_job> diag, ondiag;
     auto live = [&](uint32_t r, uint32_t c) { return r < n_igv && c < n_igv; };
     for (const ngd_tile &t : tiles) {
       const uint16_t r0 = t.ti * NGD_IG_PER_TILE, c0 = t.tj * NGD_IG_PER_TILE;
@@ -412,13 +419,18 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
             jobs.push_back(j);
           }
       } else {
-        const ngd_job d[3] = {{r0, c0, 4, 4, 1, 0}, {r0, (uint16_t)(c0 + 4), 4, 4, 0, 0},
-                              {(uint16_t)(r0 + 4), (uint16_t)(c0 + 4), 4, 4, 1, 0}};
+        const uint8_t tri = e->tri_diag ? 1 : 0;
+        const ngd_job d[3] = {{r0, c0, 4, 4, tri, 0}, {r0, (uint16_t)(c0 + 4), 4, 4, 0, 0},
+                              {(uint16_t)(r0 + 4), (uint16_t)(c0 + 4), 4, 4, tri, 0}};
         for (const ngd_job &j : d)
-          if (live(j.ig0, j.jg0)) diag.push_back(j);
+          if (live(j.ig0, j.jg0)) (j.tri ? ondiag : diag).push_back(j);
       }
     }
     for (const ngd_job &j : diag) jobs.push_back(j);
+    if (!ondiag.empty()) {
+      while (jobs.size() % 4) jobs.push_back({0, 0, 0, 0, 0, 0});  // (a workgroup of triangular blocks only)
+      for (const ngd_job &j : ondiag) jobs.push_back(j);
+    }
   }
   if (e->exact_shapes >= 3) {
     // One workgroup per slice, its wavefronts in step (accum_mfma.hip EXACT = 3 / 4): wavefront w runs on SIMD w % 4, so

@@ -446,7 +446,7 @@ def test_shards_partition_the_pairs(kernel):
 
 
 @pytest.mark.parametrize("n_ind", [17, 33, 64, 130, 200, 256, 383, 600])
-@pytest.mark.parametrize("form", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("form", [2, 3, 4, 5, 6, 7])
 def test_mfma_exact_block_forms(n_ind, form):
     """exact_shapes 2 / 3 / 4 (accum_mfma.hip EXACT): only the MFMA tiles a block needs, in blocks of up to 4 x 4, 2 x 4, or 4 x 4 with a slice's jobs in one workgroup (up to 12 jobs; else form 2):
     tiles of 16 x 16 pairs -- every pair against the oracle; called genotypes bit for bit; a bootstrap replicate as a
