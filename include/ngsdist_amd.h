@@ -97,10 +97,12 @@ typedef struct ngd_config {
                          /*     an ABSOLUTE error of <= 4e-17 per site -- 1e-9 relative wherever a pair's mean per-site    */
                          /*     term is above 4e-8.  For the reference's two matrices (parse_args.cpp:25-27, :134-137) the */
                          /*     pairs below that -- nearly identical individuals -- are then RECOMPUTED with the two-operand */
-                         /*     arithmetic (the fix-up pass: every pair whose sum is below 1e-6 x the sites visited; it    */
-                         /*     needs min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so   */
-                         /*     1e-9 relative holds at any distance; ngd_last_fixup() reports what a run recomputed, and   */
-                         /*     that nothing was if more than 4096 pairs of a matrix qualified (a data set of clones).     */
+                         /*     arithmetic (the fix-up pass: every pair whose sum is below 1e-6 x the sites visited -- under */
+                         /*     --pairwise_del x the pair's own valid sites, and never a pair without one; it needs         */
+                         /*     min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so 1e-9    */
+                         /*     relative holds at any distance; ngd_last_fixup() reports what a run recomputed, and that   */
+                         /*     nothing was if more pairs qualified than 4.1e9 pair-sites of recomputation cover (4096     */
+                         /*     pairs at 1e6 sites, every pair of a small data set: a large data set of clones is left).   */
                          /*     Any other symmetric matrix: no fix-up.  NGD_E_INVALID for an asymmetric matrix.            */
                          /* 1 = p resident, q formed for a range of sites at a time before the launch that reads it: the   */
                          /*     arithmetic of two images (sums equal to rounding, per-block partial sums bit for bit), any  */
@@ -299,8 +301,8 @@ int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
 int ngd_image_mode(const ngd_engine *e, int *fixup);
 /* The fix-up pass of the last run call (single_image = 2 engines on the reference's matrices; zeros otherwise): pairs
  * whose sum in a matrix of the job was below 1e-6 x the sites the matrix visits, how many of them were recomputed with
- * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more than
- * 4096 at once: absolute error <= 4e-17 per site), and the device time of the recomputation. */
+ * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more at
+ * once than max(4096, 4.1e9 / n_sites): absolute error <= 4e-17 per site), and the device time of the recomputation. */
 typedef struct ngd_fixup_info {
   uint64_t flagged, recomputed, skipped;
   double ms;

@@ -56,6 +56,7 @@ struct ngd_engine {
   double *d_fixparts = nullptr, *d_fixthr = nullptr;
   uint64_t cap_fixthr = 0;
   ngd_fixup_info fix_info{};
+  uint32_t fix_cap = 0;  // pairs a fix-up pass takes at most (ngd_internal.h NGD_FIX_WORK): the capacity of d_fixlist
   double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
   uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
@@ -562,7 +563,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   }
   if (e->congruent && e->sc.fix) {
     TRY(dev_alloc(e, &e->SM, g.n_sites * g.n_ind, true));
-    TRY(dev_alloc(e, &e->d_fixlist, NGD_FIX_CAP, false));
+    e->fix_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_pairs, 1u << 30),
+                                              std::max<uint64_t>(NGD_FIX_CAP, NGD_FIX_WORK / std::max<uint64_t>(1, g.n_sites)));
+    TRY(dev_alloc(e, &e->d_fixlist, e->fix_cap, false));
     TRY(dev_alloc(e, &e->d_fixcount, 1, true));
     TRY(dev_alloc(e, &e->d_fixseen, n_pairs / 32 + 1, true));
     TRY(dev_alloc(e, &e->d_fixparts, NGD_FIX_CAP, false));
@@ -975,25 +978,29 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
 //    over the MFMA pass's;
 //  * per-block partial results (d_sum == NULL): the noted pairs' entries of slab_boot, slice by slice -- the caller then
 //    forms the replicates again.
-// More than NGD_FIX_CAP noted pairs (a data set of clones): nothing is recomputed, ngd_last_fixup() says so.
+// More noted pairs than the engine's limit (fix_cap: a data set of clones): nothing is recomputed, ngd_last_fixup() says so.
 static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
                       uint32_t n_slab_slices, bool *patched) {
   if (patched) *patched = false;
   const uint32_t n = *(volatile uint32_t *)e->h_fixcount;
   e->fix_info.flagged += n;
   if (!n) return NGD_OK;
-  if (n > NGD_FIX_CAP) { e->fix_info.skipped += n; return NGD_OK; }
+  if (n > e->fix_cap) { e->fix_info.skipped += n; return NGD_OK; }
   hipEvent_t t0 = e->ev[0], t1 = e->ev[1];  // (the pass's own timings have been read)
   HIPCHK(hipEventRecord(t0, e->st));
-  if (d_sum) {
-    uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / n, (s_hi + 1023) / 1024));
-    const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
-    n_slices = (s_hi + sps - 1) / sps;
-    ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixlist, n, 0, s_hi, sps, (uint32_t)n_slices, 0, e->d_fixparts);
-    ngd_launch_fixup_finish(e->st, e->g, e->d_fixlist, n, e->d_fixparts, (uint32_t)n_slices, d_sum);
-  } else {
-    ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixlist, n, 0, s_hi, sites_per_slice, n_slab_slices, 1,
-                     e->slab_boot);
+  // NGD_FIX_CAP pairs per launch (the scratch of the partial sums; stream order: a launch's scratch is read before the next writes it)
+  for (uint32_t off = 0; off < n; off += NGD_FIX_CAP) {
+    const uint32_t m = std::min<uint32_t>(NGD_FIX_CAP, n - off);
+    if (d_sum) {
+      uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / m, (s_hi + 1023) / 1024));
+      const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
+      n_slices = (s_hi + sps - 1) / sps;
+      ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixlist + off, m, 0, s_hi, sps, (uint32_t)n_slices, 0, e->d_fixparts);
+      ngd_launch_fixup_finish(e->st, e->g, e->d_fixlist + off, m, e->d_fixparts, (uint32_t)n_slices, d_sum);
+    } else {
+      ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixlist + off, m, 0, s_hi, sites_per_slice, n_slab_slices, 1,
+                       e->slab_boot);
+    }
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(t1, e->st));
@@ -1068,16 +1075,22 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   // (without --pairwise_del the reduction writes the counts too: every pair visits the same number of sites)
   const bool cnt_in_reduce = e->kernel != NGD_KERNEL_STREAM && !e->cfg.pairwise_del;
   const bool fix = e->SM != nullptr;  // (a congruent single-image MFMA engine on one of the reference's matrices)
-  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen};
+  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen, e->fix_cap};
+  // (--pairwise_del: the pairs that want the fix-up are noted once their valid-site counts are known, below)
+  const bool fix_in_reduce = fix && !e->cfg.pairwise_del;
   if (fix) HIPCHK(hipMemsetAsync(e->d_fixcount, 0, sizeof(uint32_t), e->st));
   if (e->kernel != NGD_KERNEL_STREAM)
     ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, d_sum, cnt_in_reduce ? d_cnt : nullptr,
-                      mult ? n_drawn : n_eff, fix ? &ff : nullptr, NGD_FIX_MEAN * (double)(mult ? n_drawn : n_eff));
-  if (fix) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+                      mult ? n_drawn : n_eff, fix_in_reduce ? &ff : nullptr, NGD_FIX_MEAN * (double)(mult ? n_drawn : n_eff));
+  if (fix_in_reduce) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
   HIPCHK(hipEventRecord(e->ev[3], e->st));
   if (e->cfg.pairwise_del) {
     if (ws) ngd_launch_planes(e->st, ws, g.n_sites, g.n_words, n_planes, e->planes);
     ngd_launch_count(e->st, g, e->mask, e->planes, ws ? n_planes : 0, e->d_tiles, e->n_tiles, d_cnt);
+    if (fix) {
+      ngd_launch_fix_flag(e->st, g, d_sum, d_cnt, 1, e->d_tiles, e->n_tiles, ff);
+      HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    }
   } else if (!cnt_in_reduce) {
     ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, mult ? n_drawn : n_eff, nullptr, 1, d_cnt);
   }
@@ -1208,7 +1221,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     HIPCHK(hipMemsetAsync(d_cnt, 0, (uint64_t)n_rep * n_pairs * sizeof(unsigned long long), e->st));
   }
   const bool fix = e->SM != nullptr && mfma;  // (see pass_impl)
-  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen};
+  const ngd_fix_flags ff{e->d_fixlist, e->d_fixcount, e->d_fixseen, e->fix_cap};
   std::vector<double> thr;
   if (fix) {  // a pair is noted if its sum in ANY matrix is below NGD_FIX_MEAN x the sites that matrix visits
     thr.resize(n_rep);
@@ -1219,9 +1232,10 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     HIPCHK(hipMemsetAsync(e->d_fixcount, 0, sizeof(uint32_t), e->st));
     HIPCHK(hipMemsetAsync(e->d_fixseen, 0, (n_pairs / 32 + 1) * sizeof(uint32_t), e->st));
   }
+  const bool fix_in_reduce = fix && !pdel;  // (--pairwise_del: noted once the counts are known, below)
   ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum,
-                      fix ? &ff : nullptr, e->d_fixthr);
-  if (fix) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+                      fix_in_reduce ? &ff : nullptr, e->d_fixthr);
+  if (fix_in_reduce) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev[3], e->st));
 
@@ -1243,6 +1257,10 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(e->d_M, M.data(), M.size() * 4, hipMemcpyHostToDevice, e->st));
     ngd_launch_reduce_c(e->st, g, e->cnt_boot, (uint32_t)n_blocks, e->d_M, stride, n_rep, e->d_tiles, e->n_tiles, d_cnt);
+    if (fix) {
+      ngd_launch_fix_flag(e->st, g, d_sum, d_cnt, n_rep, e->d_tiles, e->n_tiles, ff);
+      HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    }
   } else {
     rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_rep);
     if (rc) return rc;

@@ -20,7 +20,8 @@
 //
 // One wavefront per (noted pair, slice of sites): lanes take consecutive sites, every value is its own 64-byte sector
 // of the fragment-major image (8 x the bytes of a streaming read: ~400 B per pair-site) -- a pass for the few, not for
-// the many: beyond NGD_FIX_CAP noted pairs the sums stay as the MFMA pass left them (ngd_last_fixup() reports it).
+// the many: beyond NGD_FIX_WORK pair-sites of it (ngd_internal.h: 4096 pairs at 1e6 sites, every pair of a small data set)
+// the sums stay as the MFMA pass left them (ngd_last_fixup() reports it).
 #include "ngd_internal.h"
 
 namespace {

@@ -192,11 +192,18 @@ void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *
 // (mean per-site term below NGD_FIX_MEAN: nearly identical individuals) recomputed with two-operand arithmetic from
 // p recovered out of the image T and the side array SM[site][individual] = min(p0, p2).
 #define NGD_FIX_MEAN 1e-6  // flag a pair whose sum is below this x the sites its matrix visits (error bound: 4e-17 per site)
-#define NGD_FIX_CAP 4096u  // pairs recomputed per pass at most; beyond that the sums stay as they are (ngd_last_fixup)
+#define NGD_FIX_CAP 4096u  // pairs recomputed per LAUNCH of the fix-up kernels (the size of their scratch)
+// ... and per pass as many as NGD_FIX_WORK pair-sites allow, at least NGD_FIX_CAP (ngd_engine::fix_cap): the pass streams
+// ~400 bytes per pair-site, so 4.1e9 of them -- 4096 pairs of cfg 3 -- are ~0.4 s.  A data set with more nearly identical
+// pairs than that (a data set of clones) keeps the sums of the one-image pass; ngd_last_fixup() says so.  A SMALL data
+// set may have every pair recomputed: identical called genotypes over a handful of sites are thousands of sums of
+// exactly 0, all noted (0 may be a cancelled 1e-20), and they must not crowd out the few pairs that need the pass.
+#define NGD_FIX_WORK 4096000000ull
 struct ngd_fix_flags {     // what the reduction kernels need to note the pairs that want the fix-up
-  unsigned long long *list;  // [NGD_FIX_CAP] (i << 32) | j
+  unsigned long long *list;  // [cap] (i << 32) | j
   uint32_t *count;           // pairs noted (may exceed the capacity: then the fix-up is skipped)
   uint32_t *seen;            // [n_pairs / 32 + 1] one bit per pair, for reductions that visit a pair once per replicate chunk
+  uint32_t cap;              // entries the list holds; pairs noted beyond it are counted, not listed
 };
 // out_mode 0: the partial sum of pair slot q over slice sl goes to out[q * n_slices + sl]; 1: to the slab entry
 // out[(sl * n_pad + i) * n_pad + j] (per-block partial results).  Slice sl = sites [s_lo + sl * sites_per_slice, ...) below s_hi.
@@ -216,6 +223,10 @@ void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, ui
                        uint32_t planes_per_slice, const ngd_tile *d_tiles, uint32_t n_tiles, double *d_sum,
                        unsigned long long *d_cnt = nullptr, unsigned long long cnt_value = 0,
                        const ngd_fix_flags *fix = nullptr, double fix_thr = 0);
+// --pairwise_del: the pairs of d_sum / d_cnt ([n_rep][n_pairs]) that want the fix-up pass, decided with their valid-site
+// counts in hand (a pair with no valid site in a matrix is exactly 0 there and is not noted); fix.count zeroed by the caller
+void ngd_launch_fix_flag(hipStream_t st, const ngd_geom &g, const double *d_sum, const unsigned long long *d_cnt,
+                         uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, const ngd_fix_flags &fix);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
 // fix != NULL: a pair is noted if its sum in ANY replicate r is below d_thr[r]
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(128) void k_reduce(const double *__restrict__ slab,
   // fix-up pass (fixup.hip); rare, so one atomic per noted pair
   if (fix.list && sum < fix_thr) {
     const uint32_t slot = atomicAdd(fix.count, 1u);
-    if (slot < NGD_FIX_CAP) fix.list[slot] = ((unsigned long long)i << 32) | j;
+    if (slot < fix.cap) fix.list[slot] = ((unsigned long long)i << 32) | j;
   }
 }
 
@@ -125,7 +125,32 @@ __global__ __launch_bounds__(128) void k_reduce_wb(const double *__restrict__ sl
   // single_image = 2 engines (see k_reduce): noted once, whichever replicate chunk sees a small sum first
   if (small && !((atomicOr(&fix.seen[idx >> 5], 1u << (idx & 31)) >> (idx & 31)) & 1u)) {
     const uint32_t slot = atomicAdd(fix.count, 1u);
-    if (slot < NGD_FIX_CAP) fix.list[slot] = ((unsigned long long)i << 32) | j;
+    if (slot < fix.cap) fix.list[slot] = ((unsigned long long)i << 32) | j;
+  }
+}
+
+// single_image = 2 engines under --pairwise_del (ngsDist.cpp:335-338): which pairs want the fix-up pass is decided HERE,
+// once a pair's valid-site counts are known, not in the reductions above -- a pair that shares no valid site with its
+// partner in a matrix has the sum 0 there, exactly, and must not be noted (a data set with many missing sites would
+// otherwise note thousands of empty pairs, pass the engine's limit and have the fix-up pass skipped for the few pairs that need
+// it: tools/fuzz_parity.py cases 202651, 202706, 202716, 207606).  The bound of the congruent arithmetic is per VISITED
+// site, so the threshold is per pair too: noted if, in any of the n_rep matrices, 0 < cnt and sum < mean x cnt.
+__global__ __launch_bounds__(128) void k_fix_flag(const double *__restrict__ d_sum, const unsigned long long *__restrict__ d_cnt,
+                                                   uint32_t n_rep, const ngd_tile *__restrict__ tiles, uint64_t n_ind,
+                                                   uint64_t n_pairs, double mean, ngd_fix_flags fix) {
+  const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
+  const uint32_t i = tiles[tile].ti * NGD_TILE + row;
+  const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
+  if (!(i < j && j < n_ind)) return;
+  const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+  bool small = false;
+  for (uint32_t r = 0; r < n_rep; r++) {
+    const unsigned long long c = d_cnt[(uint64_t)r * n_pairs + idx];
+    small = small || (c != 0 && d_sum[(uint64_t)r * n_pairs + idx] < mean * (double)c);
+  }
+  if (small) {
+    const uint32_t slot = atomicAdd(fix.count, 1u);
+    if (slot < fix.cap) fix.list[slot] = ((unsigned long long)i << 32) | j;
   }
 }
 
@@ -310,7 +335,14 @@ void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, ui
                        unsigned long long *d_cnt, unsigned long long cnt_value, const ngd_fix_flags *fix, double fix_thr) {
   if (!n_tiles) return;
   hipLaunchKernelGGL(k_reduce, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, slab, n_ks, planes_per_slice, d_tiles,
-                     g.n_pad, g.n_ind, d_sum, d_cnt, cnt_value, fix ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr}, fix_thr);
+                     g.n_pad, g.n_ind, d_sum, d_cnt, cnt_value, fix ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr, 0}, fix_thr);
+}
+
+void ngd_launch_fix_flag(hipStream_t st, const ngd_geom &g, const double *d_sum, const unsigned long long *d_cnt,
+                         uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, const ngd_fix_flags &fix) {
+  if (!n_tiles || !n_rep) return;
+  hipLaunchKernelGGL(k_fix_flag, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, d_sum, d_cnt, n_rep, d_tiles, g.n_ind,
+                     ngd_n_pairs(g.n_ind), NGD_FIX_MEAN, fix);
 }
 
 // replicates per pass over the partials; the weight arrays are padded to a multiple of it
@@ -320,7 +352,7 @@ void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, 
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
                          double *d_sum, const ngd_fix_flags *fix, const double *d_thr) {
   if (!n_tiles || !n_rep) return;
-  const ngd_fix_flags f = fix && d_thr ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr};
+  const ngd_fix_flags f = fix && d_thr ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr, 0};
   switch (ngd_reduce_chunk(n_rep)) {
     case 1: reduce_wb<1>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
     case 4: reduce_wb<4>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;

@@ -636,19 +636,59 @@ def test_congruent_single_image_recomputes_nearly_identical_pairs(avg_nuc_dist, 
     assert rel_err(s1[big], s2[big]) < 1e-12
 
 
+@pytest.mark.parametrize("n_sites,n_rep,B,partials", [(1, 0, 1, 0), (3, 4, 1, 2), (5, 2, 5, 1), (40, 3, 4, 2)])
+def test_congruent_single_image_fixup_ignores_pairs_without_valid_sites(n_sites, n_rep, B, partials):
+    """--pairwise_del with most sites missing (ngsDist.cpp:335-338): thousands of pairs share no valid site and have the sum 0
+    -- exactly.  They must not be noted for the fix-up pass: noted, they pass its capacity (4096 pairs) and the pass is
+    skipped for the few nearly identical pairs that need it (tools/fuzz_parity.py cases 202651, 202706, 202716, 207606:
+    2e-8 relative on the copies).  Under --pairwise_del a pair is noted once its valid-site counts are known: sum below
+    1e-6 x ITS OWN count, in any matrix of the job, and never with a count of 0."""
+    n_ind = 140
+    p = O.synth_indmajor(202716, n_ind, n_sites, miss_frac=0.9)
+    p[[3, 17, 60, 61, 99, 120, 139]] = clones(7, n_sites, 1e-9, seed=n_sites)
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    assert np.count_nonzero(co == 0) > 4096 or n_sites > 5
+    with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", single_image=2) as e:
+        e.set_option("boot_partials", partials)
+        e.upload_ind_major(p).commit()
+        s, c = e.run()
+        f = e.fixup()
+        assert f["skipped"] == 0 and f["recomputed"] == f["flagged"] >= 21
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        if n_rep:
+            maps = np.stack([N().Taus(n_sites + r).block_map(n_sites // B) for r in range(n_rep)])
+            S, Cn = e.run_batch(maps, B)
+            assert e.fixup()["skipped"] == 0
+            for r in range(n_rep):
+                sb, cb = O.all_pairs(p, pairwise_del=True, site_src=O.boot_site_src(maps[r], B), n_sites=n_sites // B * B, n_threads=8)
+                assert np.array_equal(Cn[r], cb) and rel_err(S[r], sb) < RTOL, r
+
+
 def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
-    """more pairs than the fix-up pass takes at once (4096): nothing is recomputed, the sums keep the one-image
-    arithmetic's absolute bound of 4e-17 per site (seven digits below the last one %.10f prints), and ngd_last_fixup()
-    says so; a symmetric matrix that is not one of the reference's has no fix-up pass at all"""
-    n_ind, n_sites = 100, 3000
+    """more nearly identical pairs than the fix-up pass takes (4.1e9 pair-sites of recomputation: 4096 pairs at 1e6 sites, or
+    here 44 850 pairs at 100 000): nothing is recomputed, the sums keep the one-image arithmetic's absolute bound of 4e-17
+    per site (seven digits below the last one %.10f prints), and ngd_last_fixup() says so; a SMALL data set of clones is
+    recomputed whole; a symmetric matrix that is not one of the reference's has no fix-up pass at all"""
+    n_ind, n_sites = 300, 100_000
+    p = clones(n_ind, n_sites, 1e-9)
+    sel = np.array([0, 1, 150, 299])
+    so, co = O.all_pairs(p[sel], n_threads=8)
+    with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
+        s1, c1 = e.upload_ind_major(p).commit().run()
+        f = e.fixup()
+    assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
+    pidx = lambda i, j: i * (2 * n_ind - i - 1) // 2 + (j - i - 1)  # row-major upper triangle (ngsDist.cpp:244-245)
+    got = np.array([s1[pidx(int(a), int(b))] for k, a in enumerate(sel) for b in sel[k + 1:]])
+    assert np.all(c1 == n_sites) and np.max(np.abs(got - so)) < 4e-17 * n_sites
+    assert np.array_equal(np.round(got / n_sites, 10), np.round(so / n_sites, 10))
+    n_ind, n_sites = 100, 3000  # 4950 pairs x 3000 sites: all of them recomputed, 1e-9 relative
     p = clones(n_ind, n_sites, 1e-9)
     so, co = O.all_pairs(p, n_threads=8)
     with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
         s1, c1 = e.upload_ind_major(p).commit().run()
         f = e.fixup()
-    assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
-    assert np.array_equal(c1, co) and np.max(np.abs(s1 - so)) < 4e-17 * n_sites
-    assert np.array_equal(np.round(s1 / n_sites, 10), np.round(so / n_sites, 10))
+    assert f["flagged"] == f["recomputed"] == N().n_pairs(n_ind) and f["skipped"] == 0
+    assert np.array_equal(c1, co) and rel_err(s1, so) < RTOL
     score = np.array([[0, 0.25, 1], [0.25, 0, 0.5], [1, 0.5, 0.125]])
     with N().Engine(32, n_sites, score=score, kernel="mfma", single_image=2) as e:
         assert e.image_mode() == (2, False)

@@ -32,7 +32,7 @@ for case in range(first, first + n_cases):
     partials, em_batch = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     em_spill = int(rng.integers(0, 3))  # 0 off, 1 from three matrices on, 2 from two on (table-driven EM kernel)
     spill_bytes = int(rng.choice([0, 0, 1 << 20, 3 << 20])) if em_spill else 0  # a few k-groups of terms per chunk
-    geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 7)) if kernel == "mfma" else 0,
+    geom = dict(n_slices=int(rng.choice([0, 0, 1, 3, 8, 16])), exact_shapes=int(rng.integers(0, 7)) if kernel == "mfma" else 0,  # (+ 7 below)
                 variant=int(rng.integers(0, 5)) if kernel == "em_table" else 0)
     # (drawn from a generator of their own: the cases of earlier rounds keep their shapes)
     rng_si = np.random.default_rng(7_000_000 + case)
@@ -50,6 +50,23 @@ for case in range(first, first + n_cases):
     if rng.integers(0, 4) == 0:  # called genotypes: one-hot vectors, sums must be bit-exact
         g = np.argmax(p, axis=-1)
         p = np.eye(3)[g]
+    # (round 5, a generator of its own again) exact_shapes = 7 -- triangular blocks on the diagonal of the full-pattern form --
+    # and nearly identical individuals: copies of one individual whose likelihoods are confident to eps, the pairs a
+    # one-image engine in congruent coordinates recomputes with the two-operand arithmetic (fixup.hip)
+    rng_r5 = np.random.default_rng(9_000_000 + case)
+    if kernel == "mfma" and rng_r5.integers(0, 4) == 0:
+        geom["exact_shapes"] = 7
+    if indep and n_ind >= 5 and rng_r5.integers(0, 3) == 0:
+        eps = float(rng_r5.choice([1e-7, 1e-9, 1e-13, 1e-22]))
+        n_cl = int(rng_r5.integers(2, min(n_ind, 12) + 1))
+        # (--avg_nuc_dist: two copies of a heterozygote are half a difference apart, parse_args.cpp:134-137 -- homozygotes only)
+        gcl = rng_r5.integers(0, 2, size=n_sites) * 2 if np.ravel(score)[4] != 0 else rng_r5.integers(0, 3, size=n_sites)
+        pc = eps * (1 + rng_r5.random((n_cl, n_sites, 3)))
+        pc[:, np.arange(n_sites), gcl] = 0
+        pc[:, np.arange(n_sites), gcl] = 1 - pc.sum(axis=2)
+        who = rng_r5.choice(n_ind, size=n_cl, replace=False)
+        p = p.copy()
+        p[who] = pc
     n_eff = n_sites - n_sites % B
     t = N.Taus(case)
     maps = np.stack([t.block_map(n_eff // B) for _ in range(n_rep)]) if n_rep else None
@@ -122,6 +139,15 @@ for case in range(first, first + n_cases):
             if not ok:
                 bad += 1
                 print("MISMATCH", tag, "matrix", m, flush=True)
+                if os.environ.get("NGD_FUZZ_DETAIL"):  # which check, and where
+                    w = np.flatnonzero(Cn[m] != co)
+                    print("  counts equal:", w.size == 0, w[:5], Cn[m][w[:5]], co[w[:5]])
+                    print("  finite pattern equal:", np.array_equal(np.isfinite(S[m]), fin))
+                    if fin.any():
+                        rel = np.abs(S[m] - so) / np.maximum(np.abs(so), 1e-300)
+                        rel[~fin] = 0
+                        w = np.argsort(rel)[::-1][:5]
+                        print("  worst pairs:", w, "got", S[m][w], "want", so[w], "rel", rel[w], "cnt", co[w], flush=True)
     except Exception as ex:  # noqa: BLE001
         bad += 1
         print("ERROR", tag, repr(ex), flush=True)
