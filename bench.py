@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --same_device rehearses the N>1 flow on a 1-GPU box")
     ap.add_argument("--same_device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--set_option", action="append", default=[], metavar="NAME=VALUE",
+                    help="ngd_set_option on the engine before the run (A/B measurements, e.g. sign_form=0)")
     ap.add_argument("--no_preflight", action="store_true",
                     help="N > 1: skip tools/rccl_preflight.py (the job's collectives timed once before the engine is created)")
     ap.add_argument("--shard", default="auto", choices=["auto", "replicates", "sites", "pairs"],
@@ -273,6 +275,8 @@ def main():
         eng.set_option("single_image_bytes", int(args.single_image_gb * 1e9))
     for name, v in W.get("options", {}).items():
         eng.set_option(name, v)
+    for kv in args.set_option:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     # what the engine holds: 3 = both operand images, 2 = ONE in congruent coordinates (+ the fix-up pass of nearly identical
     # pairs when `fixup`), 1 = one + the other formed a range at a time; 0 = not the MFMA kernel
     image_mode, has_fixup = eng.image_mode()
