@@ -254,7 +254,12 @@ def main():
         # the node it found, beside the RCCL version -- one "rccl_preflight {...}" line on rank 0's stderr
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from rccl_preflight import preflight
-        preflight(dist, dev, args.backend, n_mat * n_pairs, n_pairs if by_reps else 0, repeats=3)
+        try:
+            preflight(dist, dev, args.backend, n_mat * n_pairs, n_pairs if by_reps else 0, repeats=3)
+        except Exception as exc:  # (a collective that returns WRONG data is a SystemExit and ends the run; anything else --
+            # an unknown attribute of this torch build, say -- must not cost the run its bench line)
+            sys.stderr.write("rccl_preflight: rank %d: %r (the run goes on)\n" % (rank, exc))
+            sys.stderr.flush()
     n_eff = n_sites - n_sites % W["block"]
     if by_sites:
         # contiguous site ranges, whole bootstrap blocks and whole 16-site groups per rank

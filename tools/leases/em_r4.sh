@@ -4,7 +4,7 @@
 # swapstamps), bit-identity included, then where a wavefront's cycles go in both
 set -e
 rm -f /tmp/em_r4_ref.npz
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for v in "" .swap; do
   echo "== libngsdist_amd.so$v"
   NGSDIST_AMD_LIB=$PWD/ngsdist_amd/libngsdist_amd.so$v timeout -k 10 300 python3 tools/em_ab.py 20000 4 0 --ref /tmp/em_r4_ref.npz 2>&1 | grep -v amdgpu.ids

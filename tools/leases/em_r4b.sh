@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/em_r4b.sh -- wavefront priorities in the table-driven EM kernel (A/B builds fair, young of tools/build_variant.sh)
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 rm -f /tmp/em_r4_ref.npz
 for v in "" .fair .young ""; do
   echo "== libngsdist_amd.so$v"

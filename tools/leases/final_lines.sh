@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/final_lines.sh -- the bench lines committed under profiles/<round>_bench_lines/ (run on the GPU box)
 set -u
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_lines
 mkdir -p "$OUT"
 cd "$ROOT"

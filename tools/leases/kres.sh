@@ -2,7 +2,7 @@
 # tools/kres.sh <file.hip> [extra hipcc flags]: registers / spills / LDS / occupancy of every kernel in a source file
 # (hipcc -Rpass-analysis=kernel-resource-usage, one line per kernel; runs without a GPU)
 f=$1; shift
-cd "$(dirname "$0")/../ngsdist_amd/csrc" || exit 1
+cd "$(dirname "$0")/../../ngsdist_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 "$@" \
   -Rpass-analysis=kernel-resource-usage -c "$f" -o /dev/null 2>&1 | sed -e 's/ \[-Rpass[^]]*\]//g' |
   awk '/Function Name:/ {name=$NF}

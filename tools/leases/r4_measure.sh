@@ -3,7 +3,7 @@
 # command (with the unprofiled line it must reconcile with), counters of the EM kernel, the EM bootstrap job.
 # Everything lands under gpurun_out/; what is judged is copied to profiles/ by hand.
 set -u
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r4_lines
 mkdir -p "$OUT"
 cd "$ROOT"
