@@ -127,6 +127,11 @@ for case in range(first, first + n_cases):
         args += ["--max_device_bytes", (512 << 20) + 256 * n_pad * n_pad * 8 + 64 * n_ind * n_ind + 400 * max(n_ind, 24) * max(400, n_sites // 3)]
     elif how == 3:
         args += ["--prep", str(rng.choice(["host", "device"]))]
+    # (round 5, a generator of its own: earlier cases keep their command lines) the MFMA engine on one operand image in
+    # congruent coordinates + the fix-up pass of nearly identical pairs, or on two images, whatever the engine would pick
+    rng_r5 = np.random.default_rng(5_000_000 + case)
+    if kernel == "mfma":
+        args += [[], ["--single_image"], ["--two_images"], []][int(rng_r5.integers(0, 4))]
     labels = None
     lab = int(rng.integers(0, 4))
     if lab:
