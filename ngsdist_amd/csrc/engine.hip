@@ -1482,13 +1482,20 @@ static int em_spill_impl(ngd_engine *e, const uint32_t *mult, const uint32_t *mu
   HIPCHK(hipEventRecord(e->ev[2], e->st));
   ngd_launch_spill_scatter(e->st, e->d_D, (uint32_t)n_pg, e->d_tiles64, e->n_tiles64, e->d_rowpg, g.n_ind, n_mat, d_sum);
   HIPCHK(hipEventRecord(e->ev[3], e->st));
-  for (uint32_t r = 0; r < n_mat; r++) {
+  std::vector<unsigned long long> visited;  // (alive until the synchronisation below)
+  if (!e->cfg.pairwise_del) {  // every pair of matrix r counts the sites the matrix visits: one launch for the job
+    visited.resize(n_mat);
+    for (uint32_t r = 0; r < n_mat; r++) visited[r] = lead && r == 0 ? g.n_sites : drawn[r - (lead ? 1u : 0u)];
+    rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_mat);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_drawn, visited.data(), (uint64_t)n_mat * 8, hipMemcpyHostToDevice, e->st));
+    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, 0, e->d_drawn, n_mat, d_cnt);
+  }
+  for (uint32_t r = 0; r < n_mat && e->cfg.pairwise_del; r++) {
     unsigned long long *cnt_r = d_cnt + (uint64_t)r * n_pairs;
     const bool is_lead = lead && r == 0;
     const uint32_t qr = r - (lead ? 1u : 0u);
-    if (!e->cfg.pairwise_del) {
-      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, is_lead ? g.n_sites : drawn[qr], nullptr, 1, cnt_r);
-    } else if (is_lead) {
+    if (is_lead) {
       ngd_launch_count(e->st, g, e->mask, e->planes, 0, e->d_tiles, e->n_tiles, cnt_r);
     } else {
       uint32_t n_planes = 0;

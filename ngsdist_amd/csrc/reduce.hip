@@ -384,8 +384,12 @@ void ngd_launch_fill_cnt(hipStream_t st, const ngd_geom &g, const ngd_tile *d_ti
                          unsigned long long value, const unsigned long long *d_values, uint32_t n_rep,
                          unsigned long long *d_cnt) {
   if (!n_tiles || !n_rep) return;
-  hipLaunchKernelGGL(k_fill_cnt, dim3(n_tiles * NGD_TILE, n_rep), dim3(128), 0, st, d_tiles, g.n_ind, value,
-                     d_values, g.n_ind * (g.n_ind - 1) / 2, d_cnt);
+  const uint64_t n_pairs = g.n_ind * (g.n_ind - 1) / 2;
+  for (uint32_t r0 = 0; r0 < n_rep; r0 += 32768) {  // (grid.y holds 65 535)
+    const uint32_t n = n_rep - r0 < 32768 ? n_rep - r0 : 32768;
+    hipLaunchKernelGGL(k_fill_cnt, dim3(n_tiles * NGD_TILE, n), dim3(128), 0, st, d_tiles, g.n_ind, value,
+                       d_values ? d_values + r0 : nullptr, n_pairs, d_cnt + (uint64_t)r0 * n_pairs);
+  }
 }
 
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,
