@@ -289,10 +289,6 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_SINGLE_IMAGE_BYTES 8 /* [0 = 4 GB] ngd_config.single_image engines: bytes of the second operand image */
                                  /*     formed at a time (a pass is so many launches; never less than 64 k-groups per */
                                  /*     slice, or eight bootstrap blocks of a partial-sum pass); set before the first run */
-#define NGD_OPT_SIGN_FORM 9      /* [1] one-image engines on the reference's standard matrix, plain passes of the full-      */
-                                 /* pattern MFMA form: the index weights (1/2, -1/2, -1/2) as sign flips in registers and ONE  */
-                                 /* halving of the sums instead of a weight fetched and multiplied in per k-group; 0 = the     */
-                                 /* weighted instantiation (same bits: scaling by a power of two commutes with every sum)      */
 #define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
                                  /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
                                  /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */

@@ -66,14 +66,7 @@ __device__ __forceinline__ void load_frag(double &dst, uint32_t lane_off, const 
 // cfg 2 (tools/exact_diag.sh): with every job fetching its own operands a k-group took 2380 cycles -- 1810 with the
 // loads taken out, 2250 with the MFMAs taken out: the ~90 fragment loads of a k-group (47 KB through one CU's vector L1)
 // bound it, not HBM (3.4 TB/s) and not the FP64 pipe (61 % busy).
-// SIGNS (full-pattern form, one-deep ring, unweighted): the plain pass of a one-image engine on the reference's standard
-// score matrix, whose index weights are d[k % 3] = (1/2, -1/2, -1/2) (ngd_score, engine.hip).  Instead of fetching a
-// weight per k-group and multiplying the four row fragments by it (FP64 multiplies on the datapath the MFMAs use), the
-// SIGN of a lane's contraction index is flipped into its fragments -- one 32-bit XOR each, the three sign patterns of
-// k-groups 0, 1, 2 mod 3 held in registers, the k loop unrolled by three -- and the 1/2 is applied once, to the block's
-// sums (a power of two: the same bits as scaling every operand).  Slices start at, and are, multiples of three k-groups
-// (the launcher checks): no bounds test inside a trip.
-template <bool WEIGHTED, int DEPTH, int WPS, int EXACT, bool SIGNS = false>
+template <bool WEIGHTED, int DEPTH, int WPS, int EXACT>
 __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 : 256, WPS) void k_accum_mfma(
     const double *__restrict__ PA, const double *__restrict__ QB, const double *__restrict__ wk,
     const uint32_t *__restrict__ kgl, const ngd_job *__restrict__ jobs, uint32_t n_tiles /* workgroups per slice */, uint32_t n_ig,
@@ -301,37 +294,6 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
     __builtin_amdgcn_sched_barrier(0);
   };
-  // SIGNS: the full 4 x 4 pattern (upper triangle if TRI), one k-group in flight, three k-groups per trip
-  auto run_signed = [&](auto tri_c) {
-    constexpr bool TRI = decltype(tri_c)::value;
-    static_assert(!SIGNS || (DEPTH == 1 && !WEIGHTED && EXACT == 0 && WM == 4), "signs: the plain one-deep full-pattern form");
-    // contraction index k = 4 kg + (lane >> 4) carries -1/2 unless k % 3 == 0; kg0 is a multiple of 3
-    uint32_t sg[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) sg[i] = ((4u * i + ((uint32_t)lane >> 4)) % 3u) != 0 ? 0x80000000u : 0u;
-    auto flip = [](double x, uint32_t sign) {
-      return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, x) ^ ((unsigned long long)sign << 32));
-    };
-    fetch(0, kg0);
-    for (uint64_t kg = kg0; kg < kg1; kg += 3) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        arrive(0);
-#pragma unroll
-        for (int m = 0; m < WM; m++) a[0][m] = flip(a[0][m], sg[i]);
-#pragma unroll
-        for (int m = 0; m < WM; m++)
-#pragma unroll
-          for (int n = 0; n < WN; n++)
-            if (!TRI || m <= n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][m], bq[0][n], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // the refill stays BEHIND the MFMAs that read the buffer
-        fetch(0, kg + i + 1);               // (the last one of a slice: the next slice's first k-group or the images' tail)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead
-    __builtin_amdgcn_sched_barrier(0);
-  };
   // The same unit for a block of PM x PN MFMA tiles (upper triangle if TRI) with a D-deep ring: only
   // the PM + PN operand fragments it needs are loaded.  (Deeper rings for the narrow shapes were tried:
   // D = 2 and 4 lose 10-20 % to D = 1 at n_ind = 200..300.)
@@ -543,9 +505,7 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
       // 0.76), the clock falls 2.5 % and the pass is no shorter for its 8 % fewer MFMAs; holding the triangular blocks
       // back (a progress word per slice, naps) made the FULL blocks drift instead: 28 GB, and 217 GB for 39 at cfg 3
       // (profiles/r05_tri_diag_ab.txt).  Equal work per k-group is what keeps a slice's jobs together.
-      if constexpr (SIGNS) {
-        if (!job.tri) run_signed(std::false_type{}); else run_signed(std::true_type{});
-      } else if (!job.tri) run(I4{}, I4{}, std::false_type{}, std::false_type{});
+      if (!job.tri) run(I4{}, I4{}, std::false_type{}, std::false_type{});
       else if (DEPTH == 1 && PA == QB && ig0 == jg0) run(I4{}, I4{}, std::true_type{}, integral_constant<bool, DEPTH == 1>{});
       else run(I4{}, I4{}, std::true_type{}, std::false_type{});
     } else if constexpr (EXACT == 1 || EXACT == 3) {
@@ -620,7 +580,6 @@ __global__ __launch_bounds__(EXACT >= 4 ? 1024 : EXACT == 3 ? 768 : EXACT ? 64 :
         // (resume: single-image engines walk a pass in ranges of k-groups, every slice a piece of each range -- the
         // block's sums over this range are added to what the launches over the earlier ranges left in its plane)
         double v = acc[m][n][r];
-        if (SIGNS) v *= 0.5;
         if (resume) v = out[(uint64_t)i * n_pad + j] + v;
         out[(uint64_t)i * n_pad + j] = v;
       }
@@ -632,7 +591,7 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            const double *d_ws /* wk */, const uint32_t *d_kgl, const ngd_job *d_jobs, uint32_t n_wg,
                            int exact_shapes /* 3: n_wg = 1 workgroup of wg_waves wavefronts per slice */, uint32_t wg_waves, uint32_t n_ks, uint64_t kg_per_slice, uint64_t n_kg_eff,
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab, unsigned long long *d_clk,
-                           uint32_t ks0, uint32_t resume, int signs) {
+                           uint32_t ks0, uint32_t resume) {
   if (!n_wg) return;
   // EXACT = 3: a prefetching wavefront beside the jobs where a twelfth fits and the slices are plain k-group ranges
   uint32_t touch_igv = 0;
@@ -681,9 +640,6 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
     if (d_ws) NGD_MFMA(true, 1, 3, 3); else NGD_MFMA(false, 1, 3, 3);
   } else if (exact_shapes) {
     if (d_ws) NGD_MFMA(true, 1, 3, 1); else NGD_MFMA(false, 1, 3, 1);
-  } else if (signs && !d_ws && !d_kgl && !k_per_slice && !ks0 && !resume && kg_per_slice % 3 == 0 && n_kg_eff % 3 == 0) {
-    hipLaunchKernelGGL((k_accum_mfma<false, 1, 3, 0, true>), dim3(n_wg * n_ks), dim3(256), 0, st, PA, QB, d_ws, d_kgl, d_jobs, n_wg,
-                       g.n_ig, g.n_pad, kg_per_slice, n_kg_eff, k_per_slice, w_slice_stride, slab, touch_igv, d_clk, ks0, resume);
   } else {
     if (d_ws) NGD_MFMA(true, 1, 3, 0); else NGD_MFMA(false, 1, 3, 0);
   }

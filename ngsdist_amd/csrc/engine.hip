@@ -47,7 +47,6 @@ struct ngd_engine {
   // ngd_config.single_image (MFMA kernel): QB is not resident; a launch forms it for a range of k-groups at a time
   bool single_image = false;    // (ngd_config.single_image = 1: q is formed range by range)
   bool congruent = false;       // ngd_config.single_image = 2: the image holds t (sc.c, sc.d), read for both operands
-  bool sign_form = false;       // ... and sc.d is (1/2, -1/2, -1/2): a plain pass needs signs and one 1/2, no weights (NGD_OPT_SIGN_FORM)
   double *d_wD = nullptr;       // ... and these are the weights of a plain pass: sc.d[k % 3] per contraction index
   // ... and, for the reference's matrices (sc.fix), the fix-up pass of the pairs its arithmetic cannot hold to 1e-9
   // relative (fixup.hip): SM[site][individual] = min(p0, p2) beside the image, the pairs a reduction noted, scratch
@@ -543,7 +542,6 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       // matters -- the block forms of a few hundred individuals take no per-index weights in their fastest variant
       e->congruent = ok && (cfg->single_image == 2 || (e->sc.fix && e->exact_shapes == 0));
       e->sc.congruent = e->congruent ? 1 : 0;
-      e->sign_form = e->congruent && e->sc.d[0] == 0.5 && e->sc.d[1] == -0.5 && e->sc.d[2] == -0.5;
       if (!e->congruent) e->sc.fix = 0;
     }
     if (e->single_image) {  // ... and as much of the second image as the caller has memory to spare for
@@ -625,7 +623,6 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
-    if (e->congruent) e->per_slice = (e->per_slice + 11) / 12 * 12;  // ... and whole triples of k-groups (accum_mfma.hip SIGNS)
     TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
     // ([0..1] the clock sample; [2] set by a block whose shape the kernel does not list: mfma_fault())
     if (hipHostMalloc((void **)&e->h_clk, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
@@ -847,15 +844,10 @@ static int launch_accumulate(ngd_engine *e, const uint32_t *w, const uint32_t *k
     case NGD_KERNEL_MFMA:
       if (!e->single_image) {
         // (single_image = 2: both operands from the one image, the congruence's diagonal on the weights -- of a plain pass too)
-        // ... unless that diagonal is (1/2, -1/2, -1/2) -- the reference's standard matrix -- and the pass is plain, in slices
-        // of whole triples of k-groups: the full-pattern form then flips signs in registers and halves the sums once
-        // (accum_mfma.hip SIGNS; same bits), no weights fetched
-        const bool signs = e->congruent && !w && !k_per_slice && e->exact_shapes == 0 && e->sign_form && per_slice % 3 == 0 &&
-                           kg_lim % 3 == 0;
         ngd_launch_accum_mfma(e->st, g, e->PA, e->congruent ? e->PA : e->QB,
-                              k_per_slice ? e->d_wslice : (w ? e->d_wk : (e->congruent && !signs ? e->d_wD : nullptr)),
+                              k_per_slice ? e->d_wslice : (w ? e->d_wk : (e->congruent ? e->d_wD : nullptr)),
                                 (w && !k_per_slice) ? kgl : nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n_ks, per_slice,
-                                kg_lim, k_per_slice, w_stride, slab, e->d_clk, 0, 0, signs ? 1 : 0);
+                                kg_lim, k_per_slice, w_stride, slab, e->d_clk);
       } else {
         // QB is formed range by range into a scratch (k_qb_range: HBM work, 49 GB a pass at cfg 3) on the accumulation
         // kernel's own stream, each range before the launch that reads it.
@@ -1798,9 +1790,6 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       if (!e->cfg.single_image) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_SINGLE_IMAGE_BYTES needs ngd_config.single_image");
       if (!e->single_image) break;  // (another kernel, or second_image_mib holds the whole second image: nothing is formed)
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
-      break;
-    case NGD_OPT_SIGN_FORM:
-      e->sign_form = value != 0 && e->congruent && e->sc.d[0] == 0.5 && e->sc.d[1] == -0.5 && e->sc.d[2] == -0.5;
       break;
     case NGD_OPT_DEBUG_FORGE_JOB: {  // tests only: the first block of the MFMA job list gets another shape
       if (e->kernel != NGD_KERNEL_MFMA || !e->d_jobs) return fail(NGD_E_INVALID, "ngd_set_option: no MFMA job list");

@@ -138,8 +138,7 @@ void ngd_launch_accum_mfma(hipStream_t st, const ngd_geom &g, const double *PA, 
                            uint64_t k_per_slice, uint32_t w_slice_stride, double *slab,
                            unsigned long long *d_clk /* [2] or NULL: shader-cycle / constant-rate counter deltas of one wavefront */,
                            uint32_t ks0 = 0 /* the launch covers slices ks0 .. ks0 + n_ks - 1 (multiples of 8) */,
-                           uint32_t resume = 0 /* 1: every block continues from its plane of the slab (a pass in ranges) */,
-                           int signs = 0 /* full-pattern form, d_wk == NULL: index weights (1/2, -1/2, -1/2)[k % 3] as sign flips + one 1/2 */);
+                           uint32_t resume = 0 /* 1: every block continues from its plane of the slab (a pass in ranges) */);
 
 // accum_em.hip : per-site EM, one thread per pair of a 16x16 tile
 void ngd_launch_accum_em(hipStream_t st, const ngd_geom &g, const double *PA, const uint32_t *d_ws,

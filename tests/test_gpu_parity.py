@@ -720,36 +720,6 @@ def test_auto_holds_one_image_where_memory_matters():
     assert np.array_equal(c, co) and rel_err(s, so) < RTOL
 
 
-@pytest.mark.parametrize("n_ind,n_sites,n_slices", [(600, 3000, 0), (130, 1030, 8), (1000, 517, 16)])
-def test_one_image_plain_pass_by_sign_flips_carries_the_weighted_pass_bits(n_ind, n_sites, n_slices):
-    """NGD_OPT_SIGN_FORM (accum_mfma.hip SIGNS): on the reference's standard matrix the one-image engine's index weights are
-    (1/2, -1/2, -1/2) by k % 3 -- a plain pass of the full-pattern form flips signs in registers and halves the block sums
-    once instead of fetching and multiplying in a weight per k-group.  Scaling by a power of two commutes with every
-    product and sum: the two forms return the same bits (several slices, the last one short), per-block partial results
-    (the same launch path; blocks of 8 sites are whole triples of k-groups, blocks of 4 are not and keep the weights) too;
-    --avg_nuc_dist (weights 1/2, -1/2, 0) keeps the weighted form."""
-    p = O.synth_indmajor(n_ind + n_sites, n_ind, n_sites, miss_frac=0.05)
-    res = []
-    for form in (1, 0):
-        with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2, exact_shapes=1, n_slices=n_slices) as e:
-            e.set_option("sign_form", form)
-            e.upload_ind_major(p).commit()
-            r = [e.run()]
-            e.set_option("boot_partials", 2)
-            r.append(e.run(N().Taus(n_ind).block_map(n_sites // 8), 8))
-            r.append(e.run(N().Taus(n_ind).block_map(n_sites // 4), 4))
-            res.append(r)
-    for a, b in zip(*res):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    so, co = O.all_pairs(p, n_threads=8)
-    assert np.array_equal(res[0][0][1], co) and rel_err(res[0][0][0], so) < RTOL
-    score = O.score_matrix(True)
-    so, co = O.all_pairs(p, score=score, n_threads=8)
-    with N().Engine(n_ind, n_sites, score=score, kernel="mfma", single_image=2, exact_shapes=1) as e:
-        s, c = e.upload_ind_major(p).commit().run()
-    assert np.array_equal(c, co) and rel_err(s, so) < RTOL
-
-
 def test_congruent_single_image_needs_a_symmetric_score_matrix():
     """single_image = 2 rests on a congruence of the score matrix; an asymmetric one is refused (single_image = 1 takes it)"""
     score = O.score_matrix(False).copy()
