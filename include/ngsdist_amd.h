@@ -101,8 +101,9 @@ typedef struct ngd_config {
                          /*     --pairwise_del x the pair's own valid sites, and never a pair without one; it needs         */
                          /*     min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so 1e-9    */
                          /*     relative holds at any distance; ngd_last_fixup() reports what a run recomputed, and that   */
-                         /*     nothing was if more pairs qualified than 4.1e9 pair-sites of recomputation cover (4096     */
-                         /*     pairs at 1e6 sites, every pair of a small data set: a large data set of clones is left).   */
+                         /*     nothing was if more than 2^20 pairs qualified or their recomputation is more than 4.1e9    */
+                         /*     pair-sites of work (NGD_OPT_FIXUP_WORK; clusters of copies are recomputed tile by tile, 60  */
+                         /*     times cheaper than pair by pair: ~0.33 s for a cluster of 700 copies at 1e6 sites).         */
                          /*     Any other symmetric matrix: no fix-up.  NGD_E_INVALID for an asymmetric matrix.            */
                          /* 1 = p resident, q formed for a range of sites at a time before the launch that reads it: the   */
                          /*     arithmetic of two images (sums equal to rounding, per-block partial sums bit for bit), any  */
@@ -289,6 +290,9 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_SINGLE_IMAGE_BYTES 8 /* [0 = 4 GB] ngd_config.single_image engines: bytes of the second operand image */
                                  /*     formed at a time (a pass is so many launches; never less than 64 k-groups per */
                                  /*     slice, or eight bootstrap blocks of a partial-sum pass); set before the first run */
+#define NGD_OPT_FIXUP_WORK 9     /* [0 = 4.1e9] one-image engines, the fix-up pass of nearly identical pairs: its budget in  */
+                                 /* pair-sites of recomputation (a pair alone counts its sites once, a 16 x 16 tile of pairs   */
+                                 /* recomputed whole 4.3 times): above it the one-image sums stay (ngd_last_fixup: skipped)    */
 #define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
                                  /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
                                  /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */
@@ -301,8 +305,9 @@ int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
 int ngd_image_mode(const ngd_engine *e, int *fixup);
 /* The fix-up pass of the last run call (single_image = 2 engines on the reference's matrices; zeros otherwise): pairs
  * whose sum in a matrix of the job was below 1e-6 x the sites the matrix visits, how many of them were recomputed with
- * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more at
- * once than max(4096, 4.1e9 / n_sites): absolute error <= 4e-17 per site), and the device time of the recomputation. */
+ * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more than
+ * 2^20 at once, or more work than NGD_OPT_FIXUP_WORK allows: absolute error <= 4e-17 per site), and the device time of
+ * the recomputation. */
 typedef struct ngd_fixup_info {
   uint64_t flagged, recomputed, skipped;
   double ms;

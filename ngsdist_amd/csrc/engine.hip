@@ -55,8 +55,12 @@ struct ngd_engine {
   uint32_t *d_fixcount = nullptr, *d_fixseen = nullptr, *h_fixcount = nullptr;
   double *d_fixparts = nullptr, *d_fixthr = nullptr;
   uint64_t cap_fixthr = 0;
+  ngd_fix_tile *d_fixtiles = nullptr;  // 16 x 16 tiles of pairs that hold several noted pairs (fixup_pass)
+  double *d_fixtparts = nullptr;       // ... and their per-slice partial sums
+  uint64_t cap_fixtiles = 0, cap_fixtparts = 0;
   ngd_fixup_info fix_info{};
-  uint32_t fix_cap = 0;  // pairs a fix-up pass takes at most (ngd_internal.h NGD_FIX_WORK): the capacity of d_fixlist
+  uint32_t fix_cap = 0;  // pairs the reductions can note for the fix-up pass (ngd_internal.h NGD_FIX_LIST): the capacity of d_fixlist
+  uint64_t opt_fix_work = 0;  // NGD_OPT_FIXUP_WORK: the pass's budget in pair-sites (0 = NGD_FIX_WORK)
   double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
   uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
@@ -222,7 +226,7 @@ void ngd_destroy(ngd_engine *e) {
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag,
-                  e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr};
+                  e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr, e->d_fixtiles, e->d_fixtparts};
   for (void *p : ptrs)
     if (p) hipFree(p);
   for (int b = 0; b < 2; b++) {
@@ -563,8 +567,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   }
   if (e->congruent && e->sc.fix) {
     TRY(dev_alloc(e, &e->SM, g.n_sites * g.n_ind, true));
-    e->fix_cap = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(n_pairs, 1u << 30),
-                                              std::max<uint64_t>(NGD_FIX_CAP, NGD_FIX_WORK / std::max<uint64_t>(1, g.n_sites)));
+    e->fix_cap = (uint32_t)std::min<uint64_t>(n_pairs, NGD_FIX_LIST);
     TRY(dev_alloc(e, &e->d_fixlist, e->fix_cap, false));
     TRY(dev_alloc(e, &e->d_fixcount, 1, true));
     TRY(dev_alloc(e, &e->d_fixseen, n_pairs / 32 + 1, true));
@@ -978,7 +981,8 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
 //    over the MFMA pass's;
 //  * per-block partial results (d_sum == NULL): the noted pairs' entries of slab_boot, slice by slice -- the caller then
 //    forms the replicates again.
-// More noted pairs than the engine's limit (fix_cap: a data set of clones): nothing is recomputed, ngd_last_fixup() says so.
+// More noted pairs than the list holds (fix_cap), or more work than the budget (NGD_FIX_WORK / NGD_OPT_FIXUP_WORK: a large data
+// set of clones): nothing is recomputed, ngd_last_fixup() says so.
 static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
                       uint32_t n_slab_slices, bool *patched) {
   if (patched) *patched = false;
@@ -988,9 +992,68 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   if (n > e->fix_cap) { e->fix_info.skipped += n; return NGD_OK; }
   hipEvent_t t0 = e->ev[0], t1 = e->ev[1];  // (the pass's own timings have been read)
   HIPCHK(hipEventRecord(t0, e->st));
+  // Nearly identical individuals come in clusters: the noted pairs are grouped by their 16 x 16 tile of individuals on
+  // the host (a few thousand 8-byte entries), a tile that holds NGD_FIX_TILE_MIN of them or more is recomputed whole
+  // (k_fixup_tile: coalesced, 4 bytes per pair-site), the others pair by pair (k_fixup: ~400)
+  std::vector<unsigned long long> list(n);
+  HIPCHK(hipMemcpy(list.data(), e->d_fixlist, (size_t)n * 8, hipMemcpyDeviceToHost));  // (the stream is idle: the pass was waited for)
+  std::sort(list.begin(), list.end(), [](unsigned long long x, unsigned long long y) {
+    const unsigned long long tx = ((x >> 36) << 32) | ((uint32_t)x >> 4), ty = ((y >> 36) << 32) | ((uint32_t)y >> 4);
+    return tx != ty ? tx < ty : x < y;
+  });
+  std::vector<ngd_fix_tile> tiles;
+  std::vector<unsigned long long> singles;
+  for (uint32_t k = 0; k < n;) {
+    const uint32_t ig = (uint32_t)(list[k] >> 36), jg = (uint32_t)list[k] >> 4;
+    uint32_t k1 = k;
+    ngd_fix_tile t{(uint16_t)ig, (uint16_t)jg, 0, {0, 0, 0, 0}};
+    while (k1 < n && (uint32_t)(list[k1] >> 36) == ig && ((uint32_t)list[k1] >> 4) == jg) {
+      const uint32_t bit = ((uint32_t)(list[k1] >> 32) & 15) * 16 + ((uint32_t)list[k1] & 15);
+      t.mask[bit >> 6] |= 1ull << (bit & 63);
+      k1++;
+    }
+    t.n = k1 - k;
+    if (t.n >= NGD_FIX_TILE_MIN) tiles.push_back(t);
+    else singles.insert(singles.end(), list.begin() + k, list.begin() + k1);
+    k = k1;
+  }
+  {  // what the recomputation would cost, in pair-sites (ngd_internal.h NGD_FIX_WORK)
+    const double work = ((double)tiles.size() * NGD_FIX_TILE_COST_X10 / 10.0 + (double)singles.size()) * (double)s_hi;
+    if (work > (double)(e->opt_fix_work ? e->opt_fix_work : NGD_FIX_WORK)) {
+      e->fix_info.skipped += n;
+      return NGD_OK;
+    }
+  }
+  if (!tiles.empty()) {
+    int rc = ensure_cap(e, &e->d_fixtiles, &e->cap_fixtiles, tiles.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(e->d_fixtiles, tiles.data(), tiles.size() * sizeof(ngd_fix_tile), hipMemcpyHostToDevice));
+    if (d_sum) {
+      // tiles x slices of the partial-sum scratch at a time, ~4096 workgroups a launch
+      rc = ensure_cap(e, &e->d_fixtparts, &e->cap_fixtparts, (uint64_t)NGD_FIX_CAP * 256);
+      if (rc) return rc;
+      for (size_t off = 0; off < tiles.size(); off += NGD_FIX_CAP) {
+        const uint32_t m = (uint32_t)std::min<size_t>(NGD_FIX_CAP, tiles.size() - off);
+        uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / m, (s_hi + 255) / 256));
+        const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
+        n_slices = (s_hi + sps - 1) / sps;
+        ngd_launch_fixup_tiles(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixtiles + off, m, 0, s_hi, sps, (uint32_t)n_slices, 0,
+                               e->d_fixtparts);
+        ngd_launch_fixup_tiles_finish(e->st, e->g, e->d_fixtiles + off, m, e->d_fixtparts, (uint32_t)n_slices, d_sum);
+      }
+    } else {
+      for (size_t off = 0; off < tiles.size(); off += NGD_FIX_CAP) {  // (grid size: tiles x slab slices)
+        const uint32_t m = (uint32_t)std::min<size_t>(NGD_FIX_CAP, tiles.size() - off);
+        ngd_launch_fixup_tiles(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixtiles + off, m, 0, s_hi, sites_per_slice,
+                               n_slab_slices, 1, e->slab_boot);
+      }
+    }
+  }
+  const uint32_t n1 = (uint32_t)singles.size();
+  if (n1) HIPCHK(hipMemcpy(e->d_fixlist, singles.data(), (size_t)n1 * 8, hipMemcpyHostToDevice));
   // NGD_FIX_CAP pairs per launch (the scratch of the partial sums; stream order: a launch's scratch is read before the next writes it)
-  for (uint32_t off = 0; off < n; off += NGD_FIX_CAP) {
-    const uint32_t m = std::min<uint32_t>(NGD_FIX_CAP, n - off);
+  for (uint32_t off = 0; off < n1; off += NGD_FIX_CAP) {
+    const uint32_t m = std::min<uint32_t>(NGD_FIX_CAP, n1 - off);
     if (d_sum) {
       uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / m, (s_hi + 1023) / 1024));
       const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
@@ -1791,6 +1854,7 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       if (!e->single_image) break;  // (another kernel, or second_image_mib holds the whole second image: nothing is formed)
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
       break;
+    case NGD_OPT_FIXUP_WORK: e->opt_fix_work = value; break;
     case NGD_OPT_DEBUG_FORGE_JOB: {  // tests only: the first block of the MFMA job list gets another shape
       if (e->kernel != NGD_KERNEL_MFMA || !e->d_jobs) return fail(NGD_E_INVALID, "ngd_set_option: no MFMA job list");
       HIPCHK(hipSetDevice(e->device));

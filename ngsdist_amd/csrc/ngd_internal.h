@@ -192,19 +192,38 @@ void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *
 // (mean per-site term below NGD_FIX_MEAN: nearly identical individuals) recomputed with two-operand arithmetic from
 // p recovered out of the image T and the side array SM[site][individual] = min(p0, p2).
 #define NGD_FIX_MEAN 1e-6  // flag a pair whose sum is below this x the sites its matrix visits (error bound: 4e-17 per site)
-#define NGD_FIX_CAP 4096u  // pairs recomputed per LAUNCH of the fix-up kernels (the size of their scratch)
-// ... and per pass as many as NGD_FIX_WORK pair-sites allow, at least NGD_FIX_CAP (ngd_engine::fix_cap): the pass streams
-// ~400 bytes per pair-site, so 4.1e9 of them -- 4096 pairs of cfg 3 -- are ~0.4 s.  A data set with more nearly identical
-// pairs than that (a data set of clones) keeps the sums of the one-image pass; ngd_last_fixup() says so.  A SMALL data
-// set may have every pair recomputed: identical called genotypes over a handful of sites are thousands of sums of
-// exactly 0, all noted (0 may be a cancelled 1e-20), and they must not crowd out the few pairs that need the pass.
+#define NGD_FIX_CAP 4096u  // pairs (or tiles) recomputed per LAUNCH of the fix-up kernels (the size of their scratch)
+// The reductions note up to NGD_FIX_LIST pairs (ngd_engine::fix_cap: the capacity of the list); the pass then recomputes
+// them if that is at most NGD_FIX_WORK pair-sites' worth of work -- a pair recomputed alone counts its sites once
+// ([measured] 1.25e10 pair-sites/s: ~400 bytes of 64-byte sectors per pair-site), a 16 x 16 tile of pairs recomputed
+// whole counts them NGD_FIX_TILE_COST times (2.9e9 tile-sites/s) however many of its 256 pairs are noted: 4.1e9 are
+// ~0.33 s -- 4096 scattered pairs, or 950 tiles (a cluster of ~700 copies of one individual), at 1e6 sites.  Beyond
+// either bound the sums of the one-image pass stay (a LARGE data set of clones; ngd_last_fixup() says so).  A small data
+// set may have every pair recomputed: identical called genotypes over a handful of sites are thousands of sums of exactly
+// 0, all noted (0 may be a cancelled 1e-20), and they must not crowd out the few pairs that need the pass.
 #define NGD_FIX_WORK 4096000000ull
+#define NGD_FIX_LIST (1u << 20)
+#define NGD_FIX_TILE_COST_X10 43u  // (4.3)
 struct ngd_fix_flags {     // what the reduction kernels need to note the pairs that want the fix-up
   unsigned long long *list;  // [cap] (i << 32) | j
   uint32_t *count;           // pairs noted (may exceed the capacity: then the fix-up is skipped)
   uint32_t *seen;            // [n_pairs / 32 + 1] one bit per pair, for reductions that visit a pair once per replicate chunk
   uint32_t cap;              // entries the list holds; pairs noted beyond it are counted, not listed
 };
+// a 16 x 16 tile of pairs (row group ig, column group jg of 16 individuals) that holds noted pairs: bit r * 16 + c of mask
+struct ngd_fix_tile {
+  uint16_t ig, jg;
+  uint32_t n;  // noted pairs in the tile
+  unsigned long long mask[4];
+};
+#define NGD_FIX_TILE_MIN 3u  // a tile with at least this many noted pairs is recomputed whole (k_fixup_tile), the rest pair by pair
+// out_mode 0: the partial sums of tile q's 256 pairs over slice sl go to out[(q * n_slices + sl) * 256 ..]; 1: the noted pairs'
+// slab entries.  ngd_launch_fixup_tiles_finish: d_sum[pair] = the noted pairs' slices added in ascending order
+void ngd_launch_fixup_tiles(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,
+                            const uint32_t *d_ws, const ngd_fix_tile *d_tiles, uint32_t n_tiles, uint64_t s_lo, uint64_t s_hi,
+                            uint64_t sites_per_slice, uint32_t n_slices, int out_mode, double *out);
+void ngd_launch_fixup_tiles_finish(hipStream_t st, const ngd_geom &g, const ngd_fix_tile *d_tiles, uint32_t n_tiles,
+                                   const double *parts, uint32_t n_slices, double *d_sum);
 // out_mode 0: the partial sum of pair slot q over slice sl goes to out[q * n_slices + sl]; 1: to the slab entry
 // out[(sl * n_pad + i) * n_pad + j] (per-block partial results).  Slice sl = sites [s_lo + sl * sites_per_slice, ...) below s_hi.
 void ngd_launch_fixup(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,

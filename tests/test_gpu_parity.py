@@ -665,38 +665,57 @@ def test_congruent_single_image_fixup_ignores_pairs_without_valid_sites(n_sites,
 
 
 def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
-    """more nearly identical pairs than the fix-up pass takes (4.1e9 pair-sites of recomputation: 4096 pairs at 1e6 sites, or
-    here 44 850 pairs at 100 000): nothing is recomputed, the sums keep the one-image arithmetic's absolute bound of 4e-17
-    per site (seven digits below the last one %.10f prints), and ngd_last_fixup() says so; a SMALL data set of clones is
-    recomputed whole; a symmetric matrix that is not one of the reference's has no fix-up pass at all"""
-    n_ind, n_sites = 300, 100_000
-    p = clones(n_ind, n_sites, 1e-9)
-    sel = np.array([0, 1, 150, 299])
-    so, co = O.all_pairs(p[sel], n_threads=8)
-    with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
-        s1, c1 = e.upload_ind_major(p).commit().run()
-        f = e.fixup()
-    assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
-    pidx = lambda i, j: i * (2 * n_ind - i - 1) // 2 + (j - i - 1)  # row-major upper triangle (ngsDist.cpp:244-245)
-    got = np.array([s1[pidx(int(a), int(b))] for k, a in enumerate(sel) for b in sel[k + 1:]])
-    assert np.all(c1 == n_sites) and np.max(np.abs(got - so)) < 4e-17 * n_sites
-    assert np.array_equal(np.round(got / n_sites, 10), np.round(so / n_sites, 10))
-    n_ind, n_sites = 100, 3000  # 4950 pairs x 3000 sites: all of them recomputed, 1e-9 relative
+    """The fix-up pass has a budget (4.1e9 pair-sites of recomputation: ngd_internal.h NGD_FIX_WORK; NGD_OPT_FIXUP_WORK here, so
+    that the test does not need the 1200 x 400 000 copies the default takes): above it nothing is recomputed, the sums keep the
+    one-image arithmetic's absolute bound of 4e-17 per site (seven digits below the last one %.10f prints), and
+    ngd_last_fixup() says so.  Below it a data set of copies is recomputed whole -- tile by tile (clusters: 16 x 16 pairs at a
+    time, fixup.hip k_fixup_tile) and pair by pair (tiles that hold one or two noted pairs), 1e-9 relative either way.  A
+    symmetric matrix that is not one of the reference's has no fix-up pass at all."""
+    n_ind, n_sites = 100, 3000
     p = clones(n_ind, n_sites, 1e-9)
     so, co = O.all_pairs(p, n_threads=8)
+    n_tiles = 7 * 8 // 2  # 100 individuals: 7 groups of 16
     with N().Engine(n_ind, n_sites, kernel="mfma", single_image=2) as e:
+        e.set_option("fixup_work", int(4.3 * n_tiles * n_sites) - 1)  # one pair-site short of what the 28 tiles cost
         s1, c1 = e.upload_ind_major(p).commit().run()
+        f = e.fixup()
+        assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
+        assert np.array_equal(c1, co) and np.max(np.abs(s1 - so)) < 4e-17 * n_sites
+        assert np.array_equal(np.round(s1 / n_sites, 10), np.round(so / n_sites, 10))
+        e.set_option("fixup_work", 0)  # the default budget: all 4950 pairs, 28 tiles
+        s1, c1 = e.run()
         f = e.fixup()
     assert f["flagged"] == f["recomputed"] == N().n_pairs(n_ind) and f["skipped"] == 0
     assert np.array_equal(c1, co) and rel_err(s1, so) < RTOL
+    # scattered copies: pairs (0, 17), (40, 90), (41, 91) each alone in their tile, a cluster of five in one tile (10 pairs)
+    # and the cluster's pairs with individual 70 (another tile, five pairs): tiles and single pairs in one pass, with
+    # --pairwise_del, missing sites, a weighted pass and per-block partial results
+    n_ind, n_sites = 130, 2000
+    p = O.synth_indmajor(5, n_ind, n_sites, miss_frac=0.05)
+    for grp in ([0, 17], [40, 90], [41, 91], [100, 101, 102, 103, 104, 70]):
+        p[grp] = clones(len(grp), n_sites, 1e-11, seed=grp[0])
+    so, co = O.all_pairs(p, pairwise_del=True, n_threads=8)
+    with N().Engine(n_ind, n_sites, pairwise_del=True, kernel="mfma", single_image=2) as e:
+        s1, c1 = e.upload_ind_major(p).commit().run()
+        f = e.fixup()
+        assert f["recomputed"] == f["flagged"] >= 3 + 15 and f["skipped"] == 0
+        assert np.array_equal(c1, co) and rel_err(s1, so) < RTOL
+        for B, partials in ((7, 0), (8, 2)):
+            e.set_option("boot_partials", partials)
+            m = N().Taus(B).block_map(n_sites // B)
+            sb, cb = O.all_pairs(p, pairwise_del=True, site_src=O.boot_site_src(m, B), n_sites=n_sites // B * B, n_threads=8)
+            s2, c2 = e.run(m, B)
+            assert e.fixup()["recomputed"] >= 18
+            assert np.array_equal(c2, cb) and rel_err(s2, sb) < RTOL, (B, partials)
     score = np.array([[0, 0.25, 1], [0.25, 0, 0.5], [1, 0.5, 0.125]])
-    with N().Engine(32, n_sites, score=score, kernel="mfma", single_image=2) as e:
+    p = clones(100, 3000, 1e-9)
+    with N().Engine(32, 3000, score=score, kernel="mfma", single_image=2) as e:
         assert e.image_mode() == (2, False)
         s, c = e.upload_ind_major(p[:32]).commit().run()
         assert e.fixup()["flagged"] == 0
     so, co = O.all_pairs(p[:32], score=score, n_threads=8)
     assert np.array_equal(c, co) and rel_err(s, so) < RTOL  # (score[2][2] > 0: copies are not close under this matrix)
-    with N().Engine(32, n_sites, score=score, kernel="mfma") as e:  # auto: two images for such a matrix
+    with N().Engine(32, 3000, score=score, kernel="mfma") as e:  # auto: two images for such a matrix
         assert e.image_mode() == (3, False)
 
 
