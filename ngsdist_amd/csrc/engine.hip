@@ -990,6 +990,9 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   e->fix_info.flagged += n;
   if (!n) return NGD_OK;
   if (n > e->fix_cap) { e->fix_info.skipped += n; return NGD_OK; }
+  const double budget = (double)(e->opt_fix_work ? e->opt_fix_work : NGD_FIX_WORK);
+  // (the least the pass could cost -- every tile full -- before the list is fetched and sorted)
+  if ((double)((n + 255) / 256) * NGD_FIX_TILE_COST_X10 / 10.0 * (double)s_hi > budget) { e->fix_info.skipped += n; return NGD_OK; }
   hipEvent_t t0 = e->ev[0], t1 = e->ev[1];  // (the pass's own timings have been read)
   HIPCHK(hipEventRecord(t0, e->st));
   // Nearly identical individuals come in clusters: the noted pairs are grouped by their 16 x 16 tile of individuals on
@@ -1019,7 +1022,7 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   }
   {  // what the recomputation would cost, in pair-sites (ngd_internal.h NGD_FIX_WORK)
     const double work = ((double)tiles.size() * NGD_FIX_TILE_COST_X10 / 10.0 + (double)singles.size()) * (double)s_hi;
-    if (work > (double)(e->opt_fix_work ? e->opt_fix_work : NGD_FIX_WORK)) {
+    if (work > budget) {
       e->fix_info.skipped += n;
       return NGD_OK;
     }

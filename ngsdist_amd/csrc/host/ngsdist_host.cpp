@@ -100,6 +100,25 @@ static void die_engine(const char *func, int rc) {
   die(func, m.c_str());
 }
 
+// One-image engines (--single_image, or the engine's own choice: include/ngsdist_amd.h ngd_config.single_image): what the
+// fix-up pass of nearly identical pairs did in the last engine call.  Pairs it had to leave alone (more of them than its
+// budget covers: a large data set of copies of one individual) keep an ABSOLUTE error bound -- far below what "%.10f"
+// prints, but the user should know; said once.  --verbose 2: the pairs recomputed, every call.
+static void report_fixup(ngd_engine *h, uint64_t verbose) {
+  ngd_fixup_info f;
+  if (ngd_last_fixup(h, &f) != NGD_OK) return;
+  static bool warned = false;
+  if (f.skipped && !warned) {
+    warned = true;
+    fprintf(stderr, "WARNING: %lu pairs of nearly identical individuals keep the sums of the one-image pass (absolute error <= 4e-17 "
+                    "per site, not 1e-9 relative): more of them than the recomputation's budget covers; --two_images holds "
+                    "1e-9 relative on every pair.\n", (unsigned long)f.skipped);
+  }
+  if (verbose >= 2 && f.recomputed)
+    fprintf(stderr, "> %lu pairs of nearly identical individuals recomputed with the two-operand arithmetic (%.2f ms)\n",
+            (unsigned long)f.recomputed, f.ms);
+}
+
 static const char *kModelNames[] = {"Raw p-distance", "Log transf. p-distance", "JC69", "K80", "F81",
                                     "HKY85/F84", "TN93"};
 
@@ -1120,6 +1139,7 @@ int main(int argc, char **argv) {
       std::vector<uint64_t> pc(ps.size());
       int rc = ngd_run(eng.h, nullptr, 0, 0, ps.data(), pc.data());
       if (rc) die_engine("ngd_run", rc);
+      report_fixup(eng.h, p.verbose);
       for (uint64_t k = 0; k < n_comb; k++) { ts[k] += ps[k]; tc[k] += pc[k]; }
       const uint64_t blk_lo = std::min(c0, n_eff) / (B ? B : 1), blk_hi = std::min(c1, n_eff) / (B ? B : 1);
       const uint64_t nb = blk_hi - blk_lo;  // this range's blocks (none in a range of tail sites only)
@@ -1131,6 +1151,7 @@ int main(int argc, char **argv) {
           memcpy(&mpart[r * nb], &mult[(r0 + r) * n_blocks + blk_lo], nb * sizeof(uint32_t));
         rc = ngd_run_mult_batch(eng.h, mpart.data(), (uint32_t)nr, nb, B, ps.data(), pc.data());
         if (rc) die_engine("ngd_run_mult_batch", rc);
+        report_fixup(eng.h, p.verbose);
         for (uint64_t k = 0; k < nr * n_comb; k++) {
           ts[(1 + r0) * n_comb + k] += ps[k];
           tc[(1 + r0) * n_comb + k] += pc[k];
@@ -1237,6 +1258,7 @@ int main(int argc, char **argv) {
       if (with_full) {
         int rc = ngd_run(eng.h, nullptr, 0, 0, sum.data(), cnt.data());
         if (rc) die_engine("ngd_run", rc);
+        report_fixup(eng.h, p.verbose);
       }
       return;
     }
@@ -1245,11 +1267,13 @@ int main(int argc, char **argv) {
     if (!n_rep) {  // the full data alone
       int rc = ngd_run(eng.h, nullptr, 0, 0, sum.data(), cnt.data());
       if (rc) die_engine("ngd_run", rc);
+      report_fixup(eng.h, p.verbose);
       return;
     }
     int rc = with_full ? ngd_run_job(eng.h, maps, n_rep, n_blocks, p.boot_block_size, nullptr, nullptr)
                        : ngd_run_batch(eng.h, maps, n_rep, n_blocks, p.boot_block_size, nullptr, nullptr);
     if (rc) die_engine(with_full ? "ngd_run_job" : "ngd_run_batch", rc);
+    report_fixup(eng.h, p.verbose);
     in_engine = true;
   };
 

@@ -121,4 +121,12 @@ int ngd_run_mult_batch(ngd_engine *e, const uint32_t *m, uint32_t n_rep, uint64_
   (void)s;
   return fill(e, n_rep, nb, B, true, sum, cnt);
 }
+// (the host reports what the fix-up pass of a one-image engine did; the stub: a data set of 77 individuals has 5 pairs
+// left alone in its first call -- the host's warning path -- and 3 recomputed in every call)
+int ngd_last_fixup(const ngd_engine *e, ngd_fixup_info *info) {
+  if (!e || !info) return fail(NGD_E_INVALID, "stub: last_fixup");
+  *info = ngd_fixup_info{};
+  if (e->cfg.n_ind == 77) { info->flagged = 8; info->recomputed = 3; info->skipped = 5; info->ms = 0.5; }
+  return NGD_OK;
+}
 }  // extern "C"

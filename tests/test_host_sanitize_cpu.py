@@ -135,3 +135,24 @@ def test_readers_ranges_bootstrap_and_printing_under_sanitizers(san_bin, tmp_pat
     run(san_bin, tmp_path, ["--geno", cut, "--n_threads", 4] + args, ok=False)
     run(san_bin, tmp_path, ["--geno", "/nonexistent", "--n_ind", 3, "--n_sites", 3], ok=False)
     run(san_bin, tmp_path, ["--n_ind", 3, "--n_sites", 3], ok=False)
+
+
+def test_the_host_says_when_nearly_identical_pairs_were_left_alone(san_bin, tmp_path):
+    """ngd_last_fixup() after every engine call (one-image engines: include/ngsdist_amd.h): pairs the fix-up pass had to leave
+    alone are a WARNING on stderr, once per run; --verbose 2 also says what was recomputed.  The stub engine reports 5 pairs
+    left and 3 recomputed for a data set of 77 individuals, nothing for any other."""
+    rng = np.random.default_rng(3)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for n_ind, verbose, want_warn, want_info in ((77, 1, 1, 0), (77, 2, 1, 4), (24, 2, 0, 0)):
+        n_sites = 40
+        path = str(tmp_path / ("gl_%d.bin" % n_ind))
+        rng.random((n_sites, n_ind, 3)).astype(np.float64).tofile(path)
+        out = str(tmp_path / "o.dist")
+        r = subprocess.run([san_bin, "--geno", path, "--probs", "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--indep_geno",
+                            "--n_boot_rep", "3", "--boot_block_size", "4", "--out", out, "--verbose", str(verbose)],
+                           capture_output=True, env=env, timeout=300)
+        err = r.stderr.decode(errors="replace")
+        assert r.returncode == 0 and "Sanitizer" not in err and "runtime error" not in err, err[-2000:]
+        assert err.count("WARNING: 5 pairs of nearly identical individuals") == want_warn
+        assert (err.count("3 pairs of nearly identical individuals recomputed") >= 1) == (want_info > 0)
+        assert n_rows(open(out).read()) == 4 * n_ind
