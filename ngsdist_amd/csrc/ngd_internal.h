@@ -216,7 +216,7 @@ struct ngd_fix_tile {
   uint32_t n;  // noted pairs in the tile
   unsigned long long mask[4];
 };
-#define NGD_FIX_TILE_MIN 3u  // a tile with at least this many noted pairs is recomputed whole (k_fixup_tile), the rest pair by pair
+#define NGD_FIX_TILE_MIN 5u  // a tile with at least this many noted pairs is recomputed whole (k_fixup_tile: it costs what 4.3 single pairs do), the rest pair by pair
 // out_mode 0: the partial sums of tile q's 256 pairs over slice sl go to out[(q * n_slices + sl) * 256 ..]; 1: the noted pairs'
 // slab entries.  ngd_launch_fixup_tiles_finish: d_sum[pair] = the noted pairs' slices added in ascending order
 void ngd_launch_fixup_tiles(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,

@@ -669,7 +669,7 @@ def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
     that the test does not need the 1200 x 400 000 copies the default takes): above it nothing is recomputed, the sums keep the
     one-image arithmetic's absolute bound of 4e-17 per site (seven digits below the last one %.10f prints), and
     ngd_last_fixup() says so.  Below it a data set of copies is recomputed whole -- tile by tile (clusters: 16 x 16 pairs at a
-    time, fixup.hip k_fixup_tile) and pair by pair (tiles that hold one or two noted pairs), 1e-9 relative either way.  A
+    time, fixup.hip k_fixup_tile) and pair by pair (tiles that hold fewer than five noted pairs), 1e-9 relative either way.  A
     symmetric matrix that is not one of the reference's has no fix-up pass at all."""
     n_ind, n_sites = 100, 3000
     p = clones(n_ind, n_sites, 1e-9)
