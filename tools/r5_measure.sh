@@ -33,6 +33,8 @@ if [ "$PART" = lines ]; then
   line cfg4 --workload cfg4 --steps 3 --warmup 1
   line emboot --workload emboot
   line emboot_5_replicates --workload emboot --n_boot 5 --no_cpu
+  line emboot_block1 --workload emboot --block 1 --no_cpu
+  line emboot_block1_5_replicates --workload emboot --block 1 --n_boot 5 --no_cpu
   line cfg3_stream --workload cfg3 --kernel stream --steps 1 --warmup 1 --no_cpu --serial_tail
   line cfg3_two_images --workload cfg3 --single_image 3 --no_cpu
   line cfg3_single_image1 --workload cfg3 --single_image 1 --no_cpu
