@@ -100,18 +100,21 @@ typedef struct ngd_config {
                          /*     arithmetic (the fix-up pass: every pair whose sum is below 1e-6 x the sites visited -- under */
                          /*     --pairwise_del x the pair's own valid sites, and never a pair without one; it needs         */
                          /*     min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so 1e-9    */
-                         /*     relative holds at any distance; ngd_last_fixup() reports what a run recomputed, and that   */
-                         /*     nothing was if more than 2^20 pairs qualified or their recomputation is more than 4.1e9    */
-                         /*     pair-sites of work (NGD_OPT_FIXUP_WORK; clusters of copies are recomputed tile by tile, 60  */
-                         /*     times cheaper than pair by pair: ~0.33 s for a cluster of 700 copies at 1e6 sites).         */
+                         /*     relative holds at any distance, unconditionally: every qualifying pair is recomputed,      */
+                         /*     however many there are (clusters of copies tile by tile, 60 times cheaper than pair by     */
+                         /*     pair; more than 2^20 of them: every pair of the matrix, ~0.8 s at 1000 x 1e6 -- a data set  */
+                         /*     of clones).  ngd_last_fixup() reports what a run recomputed.  Only a caller that SETS a     */
+                         /*     budget (NGD_OPT_FIXUP_WORK) can have pairs left at the absolute bound.                     */
                          /*     Any other symmetric matrix: no fix-up.  NGD_E_INVALID for an asymmetric matrix.            */
                          /* 1 = p resident, q formed for a range of sites at a time before the launch that reads it: the   */
                          /*     arithmetic of two images (sums equal to rounding, per-block partial sums bit for bit), any  */
                          /*     score matrix, a fifth more time (55.6 ms at 1000 x 1e6 instead of 45.6)                    */
                          /* 3 = two images, always                                                                         */
-                         /* 0 = auto: 2 where its fix-up pass exists (the reference's matrices) and memory matters (more   */
-                         /*     than 384 padded individuals: the block forms below that take no per-index weights in their */
-                         /*     fastest variant), else two images.  ngd_image_mode() tells what an engine holds.           */
+                         /* 0 = auto: 2 where its fix-up pass exists (the reference's matrices) and the kernel runs its     */
+                         /*     full 4 x 4 block form (exact_shapes resolves to 0: more than 384 padded individuals, or    */
+                         /*     exact_shapes = 1 / 7 asked for -- the block forms of a few hundred individuals take no     */
+                         /*     per-index weights in their fastest variant), else two images.  ngd_image_mode() tells what */
+                         /*     an engine holds.                                                                           */
   uint32_t second_image_mib; /* single_image = 1: MiB of q kept resident all the same, from the first site on      */
                          /* (what the device has to spare): only the rest is formed range by range, and the extra */
                          /* time shrinks in proportion                                                             */
@@ -159,9 +162,11 @@ int ngd_commit(ngd_engine *e);
  * (ngd_upload_sites) where called genotypes must be decided bit-for-bit as on the CPU.
  *
  * Zero-copy pipeline: ngd_stage_acquire() lends one of the engine's pinned host buffers
- * (*capacity_sites sites of n_ind*3 doubles); the caller reads the file straight into it
- * and calls ngd_stage_submit(), which returns at once while the copy and the kernel run;
- * the next acquire hands out the other buffer.  ngd_upload_raw_sites() is the blocking
+ * (*capacity_sites sites of n_ind*3 doubles; a ring of NGD_OPT_STAGE_RING buffers of
+ * NGD_OPT_STAGE_PIECE_MIB MiB); the caller reads the file straight into it and calls
+ * ngd_stage_submit(), which returns at once: the copy runs on a copy stream of its own, the
+ * preparation kernel behind it on the engine's stream, and the next acquire hands out the
+ * next buffer of the ring (waiting only for the copy out of THAT buffer, a turn ago).  ngd_upload_raw_sites() is the blocking
  * convenience form.  NGD_E_NAN is reported by ngd_commit() at the latest. */
 typedef struct ngd_prep {
   int32_t in_logscale; /* --log_scale                           */
@@ -290,9 +295,13 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_SINGLE_IMAGE_BYTES 8 /* [0 = 4 GB] ngd_config.single_image engines: bytes of the second operand image */
                                  /*     formed at a time (a pass is so many launches; never less than 64 k-groups per */
                                  /*     slice, or eight bootstrap blocks of a partial-sum pass); set before the first run */
-#define NGD_OPT_FIXUP_WORK 9     /* [0 = 4.1e9] one-image engines, the fix-up pass of nearly identical pairs: its budget in  */
-                                 /* pair-sites of recomputation (a pair alone counts its sites once, a 16 x 16 tile of pairs   */
-                                 /* recomputed whole 4.3 times): above it the one-image sums stay (ngd_last_fixup: skipped)    */
+#define NGD_OPT_FIXUP_WORK 9     /* [0 = no budget: every noted pair is recomputed] one-image engines, the fix-up pass of    */
+                                 /* nearly identical pairs: a budget in pair-sites of recomputation (a pair alone counts its   */
+                                 /* sites once, a 16 x 16 tile of pairs recomputed whole 4.3 times; ~1.2e10 a second).  A run   */
+                                 /* whose noted pairs cost more keeps the one-image sums of ALL of them (absolute error <=     */
+                                 /* 4e-17 per site instead of 1e-9 relative) and says so in ngd_last_fixup().skipped           */
+#define NGD_OPT_STAGE_PIECE_MIB 10 /* [32] ngd_stage_acquire: MiB of raw input per pinned buffer                        */
+#define NGD_OPT_STAGE_RING 11     /* [6] ... and how many of them (2 .. 8); both before the first ngd_stage_acquire    */
 #define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
                                  /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
                                  /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */
@@ -304,10 +313,10 @@ int ngd_last_timing(const ngd_engine *e, ngd_timing *t);
  * engine recomputes the pairs its congruent arithmetic cannot hold to 1e-9 relative (the reference's score matrices). */
 int ngd_image_mode(const ngd_engine *e, int *fixup);
 /* The fix-up pass of the last run call (single_image = 2 engines on the reference's matrices; zeros otherwise): pairs
- * whose sum in a matrix of the job was below 1e-6 x the sites the matrix visits, how many of them were recomputed with
- * the two-operand arithmetic of ngsDist.cpp:351-353, how many were left as the one-image pass computed them (more than
- * 2^20 at once, or more work than NGD_OPT_FIXUP_WORK allows: absolute error <= 4e-17 per site), and the device time of
- * the recomputation. */
+ * whose sum in a matrix of the job was below 1e-6 x the sites the matrix visits, how many were recomputed with the
+ * two-operand arithmetic of ngsDist.cpp:351-353 (all of the engine's pairs when more than 2^20 were noted at once), how
+ * many were left as the one-image pass computed them (never, unless the caller set a budget with NGD_OPT_FIXUP_WORK and
+ * the work exceeded it: absolute error <= 4e-17 per site), and the device time of the recomputation. */
 typedef struct ngd_fixup_info {
   uint64_t flagged, recomputed, skipped;
   double ms;

@@ -8,7 +8,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ngd_internal.h"
@@ -59,8 +63,9 @@ struct ngd_engine {
   double *d_fixtparts = nullptr;       // ... and their per-slice partial sums
   uint64_t cap_fixtiles = 0, cap_fixtparts = 0;
   ngd_fixup_info fix_info{};
+  std::vector<ngd_tile> h_tiles16;  // host copy of the owned 16 x 16 tiles that hold a pair (the fix-up pass's "every pair")
   uint32_t fix_cap = 0;  // pairs the reductions can note for the fix-up pass (ngd_internal.h NGD_FIX_LIST): the capacity of d_fixlist
-  uint64_t opt_fix_work = 0;  // NGD_OPT_FIXUP_WORK: the pass's budget in pair-sites (0 = NGD_FIX_WORK)
+  uint64_t opt_fix_work = 0;  // NGD_OPT_FIXUP_WORK: the pass's budget in pair-sites (0 = none: every noted pair is recomputed)
   double *QB_res = nullptr;     // ... except its first qb_res_kg k-groups (ngd_config.second_image_mib), formed at ngd_commit()
   uint64_t qb_res_kg = 0;
   double *qb_chunk = nullptr;
@@ -124,14 +129,41 @@ struct ngd_engine {
   uint32_t n_batch_valid = 0;  // matrices of the last batch / job call, still in d_bsum / d_bcnt (ngd_fetch_matrix)
   double *staging = nullptr;
   uint64_t staging_sites = 0;
-  // raw-input pipeline: two pinned host buffers + two device buffers, alternating
-  double *pin[2] = {nullptr, nullptr}, *draw[2] = {nullptr, nullptr};
-  hipEvent_t pin_free[2] = {nullptr, nullptr};
+  // raw-input pipeline: a ring of pinned host buffers, each with its device buffer; the copies run on two streams of
+  // their own (the copy engine never waits for a preparation kernel), K0 follows each on the engine's stream
+  static constexpr int RING = 8;
+  uint64_t opt_stage_piece_mib = 32, opt_stage_ring = 6;  // NGD_OPT_STAGE_PIECE_MIB, NGD_OPT_STAGE_RING
+  double *pin[RING] = {}, *draw[RING] = {};
+  hipEvent_t pin_free[RING] = {};  // the copy out of pin[b] is done: the caller may fill it again
+  hipEvent_t k0_done[RING] = {};   // K0 has read draw[b]: the next copy may overwrite it
+  hipStream_t st_copy[2] = {nullptr, nullptr};
+  uint64_t n_staged = 0;
+  int ring_slots = 0;
+  std::thread ring_reaper;  // gives the ring back after ngd_commit, beside whatever the caller does next
   int pin_cur = 0, pin_lent = -1;
   uint64_t pin_sites = 0;
   int *d_nan = nullptr;
   bool committed = false;
   uint64_t dev_bytes = 0;
+  // Images and slabs of a GiB and more: an address range reserved at once, its physical memory created, mapped and
+  // zeroed 256 MiB at a time by a thread of the engine's own (dev_alloc_pieces, piece_worker) -- the staged load starts at
+  // once and waits, piece by piece, only for the part of an image it is about to write (piece_wait_sites).
+  enum PieceKind { PIECE_FRAG, PIECE_SITE_MAJOR, PIECE_WHOLE };  // how far into the range a site reaches
+  struct PieceRange {
+    void *va = nullptr;
+    size_t size = 0, ready = 0, n_mapped = 0;  // ready: bytes from the start that are mapped (and zeroed), under piece_mu
+    bool zero = false;
+    PieceKind kind = PIECE_WHOLE;
+    uint64_t bytes_per_site = 0;  // PIECE_SITE_MAJOR
+    std::vector<hipMemGenericAllocationHandle_t> hs;
+  };
+  std::vector<std::unique_ptr<PieceRange>> piece_ranges;
+  std::thread piece_thread;
+  std::mutex piece_mu;
+  std::condition_variable piece_cv;
+  bool piece_done = true;  // nothing left to map (or the worker gave up: piece_rc)
+  int piece_rc = 0;
+  std::string piece_err;
   ngd_timing timing{};
   // plan options (ngd_set_option)
   uint64_t opt_boot_partials = 1, opt_boot_max_bytes = 0, opt_boot_wg = 4096, opt_boot_unaligned = 1, opt_em_batch = 1;
@@ -160,6 +192,153 @@ static int dev_alloc(ngd_engine *e, T **p, uint64_t count, bool zero) {
   e->dev_bytes += count * sizeof(T);
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), e->st));
   return NGD_OK;
+}
+
+// The operand images and slabs (a GiB and more): an address range reserved at once, physical pieces of 256 MiB created,
+// mapped and zeroed behind it by a thread of the engine's own, in the order a load needs them.
+// [measured, round 6, tools/alloc_cost.hip, rocprofv3 --hip-trace of the C++ host, gpurun_out/r6/e2e_4.jsonl] On a box whose
+// device memory has been used before -- every box after its first few jobs -- the driver clears memory as it hands it out:
+// hipMalloc of cfg 3's 24.6 GB image takes 0.3 ms on pristine memory and 1.0-1.2 s otherwise (hiptrace_cfg3_3: 984 ms in
+// ONE hipMalloc; ~30 GB/s), while the link moves the file at 57 GB/s.  One allocation up front therefore cost more than the
+// whole load; piece by piece, beside the load, it costs max(clearing, load).  The pieces read at the same 5.3 TB/s as one
+// hipMalloc (tools/alloc_cost.hip) and K1m runs at the same 45.6 ms on them (gpurun_out/r6/bench_cfg3_vmm.json).
+// Anything the piecewise calls refuse up front falls back to hipMalloc; a failure later (out of memory) is reported by
+// the first call that needs the memory (ngd_stage_submit / ngd_upload_* / ngd_commit: NGD_E_NOMEM).
+// (pieces of ONE size per range: hipMemSetAccess refuses a shorter last piece -- [measured] 1 GiB + 512 MiB: invalid
+// argument; 15 x 256 MiB: fine -- so a range is rounded up to whole pieces, at most 256 MiB more than asked for)
+static const size_t kPiece = (size_t)256 << 20;
+
+static void release_pieces(ngd_engine::PieceRange &r) {
+  for (size_t c = 0; c < r.n_mapped; c++) (void)hipMemUnmap((char *)r.va + c * kPiece, std::min(kPiece, r.size - c * kPiece));
+  for (auto &h : r.hs) (void)hipMemRelease(h);
+  if (r.va) (void)hipMemAddressFree(r.va, r.size);
+  r.hs.clear();
+  r.va = nullptr;
+  r.n_mapped = 0;
+}
+
+template <typename T>
+static int dev_alloc_pieces(ngd_engine *e, T **p, uint64_t count, bool zero, ngd_engine::PieceKind kind = ngd_engine::PIECE_WHOLE,
+                            uint64_t bytes_per_site = 0) {
+  *p = nullptr;
+  const uint64_t bytes = count * sizeof(T);
+  if (bytes < ((uint64_t)1 << 30)) return dev_alloc(e, p, count, zero);
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = e->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+    (void)hipGetLastError();
+    return dev_alloc(e, p, count, zero);
+  }
+  if (kPiece % gran) return dev_alloc(e, p, count, zero);
+  std::unique_ptr<ngd_engine::PieceRange> r(new ngd_engine::PieceRange());
+  r->size = (size_t)((bytes + kPiece - 1) / kPiece * kPiece);
+  r->zero = zero;
+  r->kind = kind;
+  r->bytes_per_site = bytes_per_site;
+  if (hipMemAddressReserve(&r->va, r->size, 0, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return dev_alloc(e, p, count, zero);
+  }
+  *p = (T *)r->va;
+  e->piece_ranges.push_back(std::move(r));
+  e->dev_bytes += bytes;
+  return NGD_OK;
+}
+
+// The worker: always the piece of the range that is furthest behind (relative to its size), so that the images of a data
+// set grow together along the site axis; ranges nothing writes during a load (PIECE_WHOLE: slabs) after them.
+static void piece_worker(ngd_engine *e) {
+  auto give_up = [&](const char *what, hipError_t err) {
+    std::lock_guard<std::mutex> lk(e->piece_mu);
+    e->piece_rc = err == hipErrorOutOfMemory ? NGD_E_NOMEM : NGD_E_HIP;
+    e->piece_err = std::string("device memory, piece by piece: ") + what + ": " + hipGetErrorString(err);
+    e->piece_done = true;
+    e->piece_cv.notify_all();
+  };
+  hipError_t err = hipSetDevice(e->device);
+  if (err != hipSuccess) return give_up("hipSetDevice", err);
+  hipStream_t sa = nullptr;
+  if ((err = hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)) != hipSuccess) return give_up("hipStreamCreate", err);
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = e->device;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (;;) {
+    ngd_engine::PieceRange *r = nullptr;
+    for (int whole = 0; whole < 2 && !r; whole++) {
+      double best = 2.0;
+      for (auto &q : e->piece_ranges) {
+        if ((q->kind == ngd_engine::PIECE_WHOLE) != (whole == 1) || q->n_mapped * kPiece >= q->size) continue;
+        const double f = (double)(q->n_mapped * kPiece) / (double)q->size;
+        if (f < best) { best = f; r = q.get(); }
+      }
+    }
+    if (!r) break;
+    const size_t off = r->n_mapped * kPiece, len = std::min(kPiece, r->size - off);
+    hipMemGenericAllocationHandle_t h;
+    if ((err = hipMemCreate(&h, len, &prop, 0)) != hipSuccess) { hipStreamDestroy(sa); return give_up("hipMemCreate", err); }
+    r->hs.push_back(h);
+    if ((err = hipMemMap((char *)r->va + off, len, 0, h, 0)) != hipSuccess) { hipStreamDestroy(sa); return give_up("hipMemMap", err); }
+    r->n_mapped++;
+    if ((err = hipMemSetAccess((char *)r->va + off, len, &acc, 1)) != hipSuccess) { hipStreamDestroy(sa); return give_up("hipMemSetAccess", err); }
+    if (r->zero) {
+      if ((err = hipMemsetAsync((char *)r->va + off, 0, len, sa)) != hipSuccess || (err = hipStreamSynchronize(sa)) != hipSuccess) {
+        hipStreamDestroy(sa);
+        return give_up("zero fill", err);
+      }
+    }
+    std::lock_guard<std::mutex> lk(e->piece_mu);
+    r->ready = off + len;
+    e->piece_cv.notify_all();
+  }
+  hipStreamDestroy(sa);
+  std::lock_guard<std::mutex> lk(e->piece_mu);
+  e->piece_done = true;
+  e->piece_cv.notify_all();
+}
+
+static void piece_start(ngd_engine *e) {
+  if (e->piece_ranges.empty()) return;
+  e->piece_done = false;
+  e->piece_thread = std::thread(piece_worker, e);
+}
+
+// every piece of every range is there (or the worker has failed: its error)
+static int piece_join(ngd_engine *e) {
+  if (e->piece_thread.joinable()) e->piece_thread.join();
+  if (e->piece_rc) return fail(e->piece_rc, e->piece_err.c_str());
+  return NGD_OK;
+}
+
+// ... or only what the sites [0, s_end) of the data set reach in the ranges a load writes
+static int piece_wait_sites(ngd_engine *e, uint64_t s_end) {
+  if (e->piece_ranges.empty()) return NGD_OK;
+  std::unique_lock<std::mutex> lk(e->piece_mu);
+  for (auto &q : e->piece_ranges) {
+    size_t need = q->size;
+    if (s_end < e->g.n_sites) {
+      if (q->kind == ngd_engine::PIECE_FRAG) need = std::min<size_t>(q->size, ((3 * s_end + 3) / 4 + 1) * (size_t)e->g.n_ig * 512);
+      else if (q->kind == ngd_engine::PIECE_SITE_MAJOR) need = std::min<size_t>(q->size, (size_t)(s_end * q->bytes_per_site));
+      else if (q->va == (void *)e->slab) continue;  // (nothing of a load goes there)
+    } else if (q->va == (void *)e->slab) {
+      continue;
+    }
+    e->piece_cv.wait(lk, [&] { return q->ready >= need || e->piece_done; });
+    if (e->piece_rc) return fail(e->piece_rc, e->piece_err.c_str());
+  }
+  return NGD_OK;
+}
+
+static bool in_pieces(const ngd_engine *e, const void *p) {
+  for (auto &r : e->piece_ranges)
+    if (r->va == p) return true;
+  return false;
 }
 
 // grow-only device scratch
@@ -219,21 +398,29 @@ uint64_t ngd_n_pairs(uint64_t n_ind) { return n_ind * (n_ind - 1) / 2; }
 uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2) { return ngd_pair_idx(n_ind, i1, i2); }
 uint64_t ngd_device_bytes(const ngd_engine *e) { return e ? e->dev_bytes : 0; }
 
+static void stage_reap(ngd_engine *e);
+
 void ngd_destroy(ngd_engine *e) {
   if (!e) return;
   hipSetDevice(e->device);
+  if (e->piece_thread.joinable()) e->piece_thread.join();
   if (e->st) hipStreamSynchronize(e->st);
+  stage_reap(e);
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag,
                   e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr, e->d_fixtiles, e->d_fixtparts};
   for (void *p : ptrs)
-    if (p) hipFree(p);
-  for (int b = 0; b < 2; b++) {
+    if (p && !in_pieces(e, p)) hipFree(p);
+  for (auto &r : e->piece_ranges) release_pieces(*r);
+  for (int b = 0; b < ngd_engine::RING; b++) {
     if (e->pin[b]) hipHostFree(e->pin[b]);
     if (e->draw[b]) hipFree(e->draw[b]);
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
+    if (e->k0_done[b]) hipEventDestroy(e->k0_done[b]);
   }
+  for (int c = 0; c < 2; c++)
+    if (e->st_copy[c]) hipStreamDestroy(e->st_copy[c]);
   if (e->h_clk) hipHostFree(e->h_clk);
   if (e->h_fixcount) hipHostFree(e->h_fixcount);
   if (e->d_nan) hipFree(e->d_nan);
@@ -501,6 +688,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   } while (0)
   TRY(dev_alloc(e, &e->d_tiles, tiles.size(), false));
   TRY(dev_alloc(e, &e->d_tiles16, tiles16.size(), false));
+  e->h_tiles16 = tiles16;
   TRY(dev_alloc(e, &e->d_tiles64, tiles64.size(), false));
   TRY(dev_alloc(e, &e->d_pairs, pairs.size(), false));
   TRY(dev_alloc(e, &e->d_jobs, jobs.size(), false));
@@ -523,9 +711,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
 
   // ---- resident images (zero-filled: padding individuals/sites contribute nothing) ----
   if (kernel == NGD_KERNEL_STREAM) {
-    TRY(dev_alloc(e, &e->PI, g.n_ind * g.n_sites_pad * 3, true));
+    TRY(dev_alloc_pieces(e, &e->PI, g.n_ind * g.n_sites_pad * 3, true));  // (a row of sites per individual: a load needs all of it)
   } else {
-    TRY(dev_alloc(e, &e->PA, frag_elems, true));
+    TRY(dev_alloc_pieces(e, &e->PA, frag_elems, true, ngd_engine::PIECE_FRAG));
     e->single_image = kernel == NGD_KERNEL_MFMA && cfg->single_image == 1;
     if (kernel == NGD_KERNEL_MFMA && (cfg->single_image == 2 || cfg->single_image == 0)) {
       const bool ok = ngd_score_congruence(cfg->score, e->sc.c, e->sc.d) == NGD_OK;
@@ -552,7 +740,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
       e->qb_res_kg = std::min<uint64_t>(g.n_kg, ((uint64_t)cfg->second_image_mib << 20) / ((uint64_t)g.n_ig * 64 * 8));
       if (e->qb_res_kg == g.n_kg) { e->single_image = false; e->qb_res_kg = 0; }  // all of it: the two-image engine
     }
-    if (kernel == NGD_KERNEL_MFMA && !e->single_image && !e->congruent) TRY(dev_alloc(e, &e->QB, frag_elems, true));
+    if (kernel == NGD_KERNEL_MFMA && !e->single_image && !e->congruent) TRY(dev_alloc_pieces(e, &e->QB, frag_elems, true, ngd_engine::PIECE_FRAG));
     if (e->qb_res_kg) TRY(dev_alloc(e, &e->QB_res, (e->qb_res_kg + NGD_KG_TAIL) * (uint64_t)g.n_ig * 64, false));
   }
   if (cfg->pairwise_del) {
@@ -566,7 +754,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     ngd_launch_index_weights(e->st, 4 * (g.n_kg + NGD_KG_TAIL), e->sc.d, e->d_wD);
   }
   if (e->congruent && e->sc.fix) {
-    TRY(dev_alloc(e, &e->SM, g.n_sites * g.n_ind, true));
+    TRY(dev_alloc_pieces(e, &e->SM, g.n_sites * g.n_ind, true, ngd_engine::PIECE_SITE_MAJOR, g.n_ind * 8));
     e->fix_cap = (uint32_t)std::min<uint64_t>(n_pairs, NGD_FIX_LIST);
     TRY(dev_alloc(e, &e->d_fixlist, e->fix_cap, false));
     TRY(dev_alloc(e, &e->d_fixcount, 1, true));
@@ -626,7 +814,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     ks = std::max<uint64_t>(8, (ks + 7) / 8 * 8);
     e->n_ks = (uint32_t)ks;
     e->per_slice = ((g.n_kg + ks - 1) / ks + 3) / 4 * 4;  // whole pipeline trips (accum_mfma.hip DEPTH)
-    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+    TRY(dev_alloc_pieces(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
     // ([0..1] the clock sample; [2] set by a block whose shape the kernel does not list: mfma_fault())
     if (hipHostMalloc((void **)&e->h_clk, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&e->d_clk, e->h_clk, 0) != hipSuccess)
@@ -692,6 +880,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   TRY(dev_alloc(e, &e->staging, e->staging_sites * g.n_ind * 3, false));
 #undef TRY
   if (hipStreamSynchronize(e->st) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: sync failed"));
+  piece_start(e);  // the images' and slabs' memory arrives behind this call (dev_alloc_pieces)
   *out = e;
   return NGD_OK;
 }
@@ -701,6 +890,7 @@ static int upload_common(ngd_engine *e, const double *p, int ind_major, uint64_t
   if (e->committed) return fail(NGD_E_INVALID, "upload: data set already committed");
   if (s0 + n > e->g.n_sites || s0 + n < s0) return fail(NGD_E_INVALID, "upload: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
+  if (int rc = piece_join(e)) return rc;
   const uint64_t n_ind = e->g.n_ind;
   for (uint64_t done = 0; done < n;) {
     const uint64_t c = std::min(e->staging_sites, n - done);
@@ -729,17 +919,37 @@ int ngd_upload_ind_major(ngd_engine *e, const double *p) {
   return upload_common(e, p, 1, 0, e->g.n_sites);
 }
 
+// [measured, round 6] `tools/host_read_pipeline`: pieces of 32-64 MiB through a ring of 4-8 pinned buffers keep the copy
+// engine at the link's rate (56.9 of 57.6 GB/s) while the caller fills the next ones; one piece costs 0.6-1.1 ms of copy,
+// far above a launch.  Pinned memory is allocated at ~6.5 GiB/s, so the ring is kept to 192 MiB.
+// A slot is allocated when the ring first comes to it: the copy engine is then already busy with the slots before it
+// (6 x (hipHostMalloc + hipMalloc) up front were 40-50 ms before the first byte moved).
+static void stage_reap(ngd_engine *e) {
+  if (e->ring_reaper.joinable()) e->ring_reaper.join();
+}
+
 static int stage_init(ngd_engine *e) {
-  if (e->pin[0]) return NGD_OK;
-  e->pin_sites = std::max<uint64_t>(1, std::min<uint64_t>(e->g.n_sites, (128ull << 20) / (e->g.n_ind * 24)));
-  const uint64_t bytes = e->pin_sites * e->g.n_ind * 24;
-  for (int b = 0; b < 2; b++) {
-    HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
-    int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
-    if (rc) return rc;
-    HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
-  }
+  if (e->pin_sites) return NGD_OK;
+  stage_reap(e);
+  e->pin_sites = std::max<uint64_t>(1, std::min<uint64_t>(e->g.n_sites, (e->opt_stage_piece_mib << 20) / (e->g.n_ind * 24)));
+  // (a data set of fewer pieces than the ring has slots takes only that many)
+  e->ring_slots = (int)std::min<uint64_t>(e->opt_stage_ring, (e->g.n_sites + e->pin_sites - 1) / e->pin_sites);
+  for (int c = 0; c < 2; c++)
+    if (!e->st_copy[c]) HIPCHK(hipStreamCreateWithFlags(&e->st_copy[c], hipStreamNonBlocking));
+  e->n_staged = 0;
+  e->pin_cur = 0;
   return e->d_nan ? NGD_OK : dev_alloc(e, &e->d_nan, 1, true);
+}
+
+static int stage_slot(ngd_engine *e, int b) {
+  if (e->pin[b]) return NGD_OK;
+  const uint64_t bytes = e->pin_sites * e->g.n_ind * 24;
+  HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
+  int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
+  if (rc) return rc;
+  HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->k0_done[b], hipEventDisableTiming));
+  return NGD_OK;
 }
 
 int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites) {
@@ -749,7 +959,9 @@ int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites
   int rc = stage_init(e);
   if (rc) return rc;
   const int b = e->pin_cur;
-  HIPCHK(hipEventSynchronize(e->pin_free[b]));  // the copy out of this buffer (two submits ago) is done
+  rc = stage_slot(e, b);
+  if (rc) return rc;
+  HIPCHK(hipEventSynchronize(e->pin_free[b]));  // the copy out of this buffer (a turn of the ring ago) is done
   e->pin_lent = b;
   *host_buf = e->pin[b];
   *capacity_sites = e->pin_sites;
@@ -765,14 +977,19 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
     return fail(NGD_E_INVALID, "ngd_stage_submit: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
   const int b = e->pin_lent;
-  HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, e->st));
-  HIPCHK(hipEventRecord(e->pin_free[b], e->st));
+  hipStream_t cs = e->st_copy[e->n_staged++ & 1];
+  HIPCHK(hipStreamWaitEvent(cs, e->k0_done[b], 0));  // (never recorded yet: no wait)
+  HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, cs));
+  HIPCHK(hipEventRecord(e->pin_free[b], cs));
+  HIPCHK(hipStreamWaitEvent(e->st, e->pin_free[b], 0));
+  if (int rc = piece_wait_sites(e, s0 + n)) return rc;  // (the part of the images these sites are written to is mapped)
   ngd_launch_prep_layout(e->st, e->g, e->draw[b], s0, n, prep->in_logscale, prep->call_geno, prep->N_thresh,
                          prep->call_thresh, e->sc, e->cfg.pairwise_del, e->PA, e->QB, e->congruent ? e->SM : e->PI, e->mask,
                          e->d_nan);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->k0_done[b], e->st));
   e->pin_lent = -1;
-  e->pin_cur = b ^ 1;
+  e->pin_cur = (b + 1) % e->ring_slots;
   return NGD_OK;
 }
 
@@ -795,14 +1012,33 @@ int ngd_upload_raw_sites(ngd_engine *e, const double *raw, uint64_t s0, uint64_t
 int ngd_commit(ngd_engine *e) {
   if (!e) return fail(NGD_E_INVALID, "ngd_commit: null engine");
   HIPCHK(hipSetDevice(e->device));
+  if (int rc = piece_join(e)) return rc;
   HIPCHK(hipStreamSynchronize(e->st));
   if (e->d_nan) {
     int flag = 0;
     HIPCHK(hipMemcpy(&flag, e->d_nan, sizeof(int), hipMemcpyDeviceToHost));
-    for (int b = 0; b < 2; b++) {  // the pipeline is over: give its buffers back
-      if (e->pin[b]) { HIPCHK(hipHostFree(e->pin[b])); e->pin[b] = nullptr; }
-      if (e->draw[b]) { HIPCHK(hipFree(e->draw[b])); e->draw[b] = nullptr; e->dev_bytes -= e->pin_sites * e->g.n_ind * 24; }
-      if (e->pin_free[b]) { HIPCHK(hipEventDestroy(e->pin_free[b])); e->pin_free[b] = nullptr; }
+    {  // the pipeline is over: its buffers go back on a thread of their own (6 x hipHostFree + hipFree are ~30 ms)
+      struct Slot { double *pin, *draw; hipEvent_t a, b; };
+      std::vector<Slot> slots;
+      for (int b = 0; b < ngd_engine::RING; b++) {
+        if (e->pin[b] || e->draw[b]) slots.push_back({e->pin[b], e->draw[b], e->pin_free[b], e->k0_done[b]});
+        if (e->draw[b]) e->dev_bytes -= e->pin_sites * e->g.n_ind * 24;
+        e->pin[b] = nullptr; e->draw[b] = nullptr; e->pin_free[b] = nullptr; e->k0_done[b] = nullptr;
+      }
+      e->pin_sites = 0;
+      e->ring_slots = 0;
+      stage_reap(e);
+      const int dev = e->device;
+      if (!slots.empty())
+        e->ring_reaper = std::thread([slots, dev]() {
+          (void)hipSetDevice(dev);
+          for (const Slot &s : slots) {
+            if (s.pin) (void)hipHostFree(s.pin);
+            if (s.draw) (void)hipFree(s.draw);
+            if (s.a) (void)hipEventDestroy(s.a);
+            if (s.b) (void)hipEventDestroy(s.b);
+          }
+        });
     }
     e->pin_cur = 0;
     e->pin_lent = -1;
@@ -827,6 +1063,7 @@ int ngd_synth_fill_range(ngd_engine *e, uint64_t seed, double miss_frac, uint64_
   if (!e) return fail(NGD_E_INVALID, "ngd_synth_fill: null engine");
   if (e->committed) return fail(NGD_E_INVALID, "ngd_synth_fill: data set already committed");
   HIPCHK(hipSetDevice(e->device));
+  if (int rc = piece_join(e)) return rc;
   ngd_launch_synth(e->st, e->g, seed, miss_frac, site0, e->sc, e->cfg.pairwise_del, e->PA, e->QB,
                    e->congruent ? e->SM : e->PI, e->mask);
   HIPCHK(hipGetLastError());
@@ -981,72 +1218,100 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
 //    over the MFMA pass's;
 //  * per-block partial results (d_sum == NULL): the noted pairs' entries of slab_boot, slice by slice -- the caller then
 //    forms the replicates again.
-// More noted pairs than the list holds (fix_cap), or more work than the budget (NGD_FIX_WORK / NGD_OPT_FIXUP_WORK: a large data
-// set of clones): nothing is recomputed, ngd_last_fixup() says so.
+// The tolerance is unconditional: EVERY noted pair is recomputed, in launches of bounded size, however many there are
+// (round 6; rounds 4-5 gave up on all of them past a budget of ~0.33 s).  More noted pairs than the list holds (fix_cap):
+// which ones is then unknown, and every tile of the upper triangle is recomputed whole -- the whole matrix in gen_dist()'s
+// own arithmetic ([measured] 6-7e11 pair-sites/s: ~0.8 s at cfg 3's size, for a data set of clones).  Only a caller who
+// SETS a budget (NGD_OPT_FIXUP_WORK != 0) gets the old behaviour: noted work above it is left as the one-image pass
+// computed it and ngd_last_fixup() reports the pairs as skipped.
+// A pair's slices depend on the number of sites alone (not on how many other pairs were noted), so its recomputed bits do
+// not depend on the rest of the data set.
 static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
                       uint32_t n_slab_slices, bool *patched) {
   if (patched) *patched = false;
   const uint32_t n = *(volatile uint32_t *)e->h_fixcount;
   e->fix_info.flagged += n;
   if (!n) return NGD_OK;
-  if (n > e->fix_cap) { e->fix_info.skipped += n; return NGD_OK; }
-  const double budget = (double)(e->opt_fix_work ? e->opt_fix_work : NGD_FIX_WORK);
+  const bool capped = e->opt_fix_work != 0;  // a budget is a caller's explicit leave to skip
+  const double budget = (double)e->opt_fix_work;
+  const bool all = n > e->fix_cap;  // the list overflowed: which pairs were noted is not known
+  const double tile_cost = NGD_FIX_TILE_COST_X10 / 10.0 * (double)s_hi;
   // (the least the pass could cost -- every tile full -- before the list is fetched and sorted)
-  if ((double)((n + 255) / 256) * NGD_FIX_TILE_COST_X10 / 10.0 * (double)s_hi > budget) { e->fix_info.skipped += n; return NGD_OK; }
+  if (capped && (all ? (double)e->h_tiles16.size() : (double)((n + 255) / 256)) * tile_cost > budget) {
+    e->fix_info.skipped += n;
+    return NGD_OK;
+  }
   hipEvent_t t0 = e->ev[0], t1 = e->ev[1];  // (the pass's own timings have been read)
   HIPCHK(hipEventRecord(t0, e->st));
-  // Nearly identical individuals come in clusters: the noted pairs are grouped by their 16 x 16 tile of individuals on
-  // the host (a few thousand 8-byte entries), a tile that holds NGD_FIX_TILE_MIN of them or more is recomputed whole
-  // (k_fixup_tile: coalesced, 4 bytes per pair-site), the others pair by pair (k_fixup: ~400)
-  std::vector<unsigned long long> list(n);
-  HIPCHK(hipMemcpy(list.data(), e->d_fixlist, (size_t)n * 8, hipMemcpyDeviceToHost));  // (the stream is idle: the pass was waited for)
-  std::sort(list.begin(), list.end(), [](unsigned long long x, unsigned long long y) {
-    const unsigned long long tx = ((x >> 36) << 32) | ((uint32_t)x >> 4), ty = ((y >> 36) << 32) | ((uint32_t)y >> 4);
-    return tx != ty ? tx < ty : x < y;
-  });
   std::vector<ngd_fix_tile> tiles;
   std::vector<unsigned long long> singles;
-  for (uint32_t k = 0; k < n;) {
-    const uint32_t ig = (uint32_t)(list[k] >> 36), jg = (uint32_t)list[k] >> 4;
-    uint32_t k1 = k;
-    ngd_fix_tile t{(uint16_t)ig, (uint16_t)jg, 0, {0, 0, 0, 0}};
-    while (k1 < n && (uint32_t)(list[k1] >> 36) == ig && ((uint32_t)list[k1] >> 4) == jg) {
-      const uint32_t bit = ((uint32_t)(list[k1] >> 32) & 15) * 16 + ((uint32_t)list[k1] & 15);
-      t.mask[bit >> 6] |= 1ull << (bit & 63);
-      k1++;
+  if (all) {
+    for (const ngd_tile &t16 : e->h_tiles16) {  // (this engine's shard of the pairs)
+        const uint32_t ig = t16.ti, jg = t16.tj;
+        ngd_fix_tile t{(uint16_t)ig, (uint16_t)jg, 0, {0, 0, 0, 0}};
+        for (uint32_t r = 0; r < 16; r++)
+          for (uint32_t c = 0; c < 16; c++) {
+            const uint64_t i = (uint64_t)ig * 16 + r, j = (uint64_t)jg * 16 + c;
+            if (i < j && j < e->g.n_ind) { t.mask[(r * 16 + c) >> 6] |= 1ull << ((r * 16 + c) & 63); t.n++; }
+          }
+        if (t.n) tiles.push_back(t);
+      }
+  } else {
+    // Nearly identical individuals come in clusters: the noted pairs are grouped by their 16 x 16 tile of individuals on
+    // the host (8-byte entries), a tile that holds NGD_FIX_TILE_MIN of them or more is recomputed whole (k_fixup_tile:
+    // coalesced, 4 bytes per pair-site), the others pair by pair (k_fixup: ~400)
+    std::vector<unsigned long long> list(n);
+    HIPCHK(hipMemcpy(list.data(), e->d_fixlist, (size_t)n * 8, hipMemcpyDeviceToHost));  // (the stream is idle: the pass was waited for)
+    std::sort(list.begin(), list.end(), [](unsigned long long x, unsigned long long y) {
+      const unsigned long long tx = ((x >> 36) << 32) | ((uint32_t)x >> 4), ty = ((y >> 36) << 32) | ((uint32_t)y >> 4);
+      return tx != ty ? tx < ty : x < y;
+    });
+    for (uint32_t k = 0; k < n;) {
+      const uint32_t ig = (uint32_t)(list[k] >> 36), jg = (uint32_t)list[k] >> 4;
+      uint32_t k1 = k;
+      ngd_fix_tile t{(uint16_t)ig, (uint16_t)jg, 0, {0, 0, 0, 0}};
+      while (k1 < n && (uint32_t)(list[k1] >> 36) == ig && ((uint32_t)list[k1] >> 4) == jg) {
+        const uint32_t bit = ((uint32_t)(list[k1] >> 32) & 15) * 16 + ((uint32_t)list[k1] & 15);
+        t.mask[bit >> 6] |= 1ull << (bit & 63);
+        k1++;
+      }
+      t.n = k1 - k;
+      if (t.n >= NGD_FIX_TILE_MIN) tiles.push_back(t);
+      else singles.insert(singles.end(), list.begin() + k, list.begin() + k1);
+      k = k1;
     }
-    t.n = k1 - k;
-    if (t.n >= NGD_FIX_TILE_MIN) tiles.push_back(t);
-    else singles.insert(singles.end(), list.begin() + k, list.begin() + k1);
-    k = k1;
   }
-  {  // what the recomputation would cost, in pair-sites (ngd_internal.h NGD_FIX_WORK)
-    const double work = ((double)tiles.size() * NGD_FIX_TILE_COST_X10 / 10.0 + (double)singles.size()) * (double)s_hi;
-    if (work > budget) {
-      e->fix_info.skipped += n;
-      return NGD_OK;
-    }
+  // what the recomputation costs, in pair-sites (ngd_internal.h)
+  if (capped && (double)tiles.size() * tile_cost + (double)singles.size() * (double)s_hi > budget) {
+    e->fix_info.skipped += n;
+    return NGD_OK;
   }
+  // launches of at most 2^22 workgroups (HIP bounds a launch's threads by 2^32); a pass over per-block partial results has
+  // one workgroup per (tile or pair, slab slice)
+  const uint64_t max_wg = 1ull << 22;
+  if (!d_sum && n_slab_slices > max_wg) return fail(NGD_E_INVALID, "fix-up pass: more slab slices than a launch has workgroups");
   if (!tiles.empty()) {
     int rc = ensure_cap(e, &e->d_fixtiles, &e->cap_fixtiles, tiles.size());
     if (rc) return rc;
     HIPCHK(hipMemcpy(e->d_fixtiles, tiles.data(), tiles.size() * sizeof(ngd_fix_tile), hipMemcpyHostToDevice));
     if (d_sum) {
-      // tiles x slices of the partial-sum scratch at a time, ~4096 workgroups a launch
+      // slices of 4096 sites (fewer, longer ones only where NGD_FIX_CAP of them would not cover the sites); as many tiles
+      // to a launch as the partial-sum scratch holds (stream order: a launch's scratch is read before the next writes it)
       rc = ensure_cap(e, &e->d_fixtparts, &e->cap_fixtparts, (uint64_t)NGD_FIX_CAP * 256);
       if (rc) return rc;
-      for (size_t off = 0; off < tiles.size(); off += NGD_FIX_CAP) {
-        const uint32_t m = (uint32_t)std::min<size_t>(NGD_FIX_CAP, tiles.size() - off);
-        uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / m, (s_hi + 255) / 256));
-        const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
-        n_slices = (s_hi + sps - 1) / sps;
+      const uint64_t sps = std::max<uint64_t>(4096, (s_hi + NGD_FIX_CAP - 1) / NGD_FIX_CAP);
+      const uint64_t n_slices = (s_hi + sps - 1) / sps;
+      const size_t per = std::max<size_t>(1, NGD_FIX_CAP / n_slices);
+      for (size_t off = 0; off < tiles.size(); off += per) {
+        const uint32_t m = (uint32_t)std::min<size_t>(per, tiles.size() - off);
         ngd_launch_fixup_tiles(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixtiles + off, m, 0, s_hi, sps, (uint32_t)n_slices, 0,
                                e->d_fixtparts);
         ngd_launch_fixup_tiles_finish(e->st, e->g, e->d_fixtiles + off, m, e->d_fixtparts, (uint32_t)n_slices, d_sum);
       }
     } else {
-      for (size_t off = 0; off < tiles.size(); off += NGD_FIX_CAP) {  // (grid size: tiles x slab slices)
-        const uint32_t m = (uint32_t)std::min<size_t>(NGD_FIX_CAP, tiles.size() - off);
+      const size_t per = (size_t)std::max<uint64_t>(1, max_wg / n_slab_slices);
+      for (size_t off = 0; off < tiles.size(); off += per) {
+        const uint32_t m = (uint32_t)std::min<size_t>(per, tiles.size() - off);
         ngd_launch_fixup_tiles(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixtiles + off, m, 0, s_hi, sites_per_slice,
                                n_slab_slices, 1, e->slab_boot);
       }
@@ -1054,16 +1319,19 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   }
   const uint32_t n1 = (uint32_t)singles.size();
   if (n1) HIPCHK(hipMemcpy(e->d_fixlist, singles.data(), (size_t)n1 * 8, hipMemcpyHostToDevice));
-  // NGD_FIX_CAP pairs per launch (the scratch of the partial sums; stream order: a launch's scratch is read before the next writes it)
-  for (uint32_t off = 0; off < n1; off += NGD_FIX_CAP) {
-    const uint32_t m = std::min<uint32_t>(NGD_FIX_CAP, n1 - off);
-    if (d_sum) {
-      uint64_t n_slices = std::max<uint64_t>(1, std::min<uint64_t>(NGD_FIX_CAP / m, (s_hi + 1023) / 1024));
-      const uint64_t sps = (s_hi + n_slices - 1) / n_slices;
-      n_slices = (s_hi + sps - 1) / sps;
+  if (n1 && d_sum) {
+    const uint64_t sps = std::max<uint64_t>(1024, (s_hi + NGD_FIX_CAP - 1) / NGD_FIX_CAP);
+    const uint64_t n_slices = (s_hi + sps - 1) / sps;
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, NGD_FIX_CAP / n_slices);
+    for (uint32_t off = 0; off < n1; off += per) {
+      const uint32_t m = std::min<uint32_t>(per, n1 - off);
       ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, ws, e->d_fixlist + off, m, 0, s_hi, sps, (uint32_t)n_slices, 0, e->d_fixparts);
       ngd_launch_fixup_finish(e->st, e->g, e->d_fixlist + off, m, e->d_fixparts, (uint32_t)n_slices, d_sum);
-    } else {
+    }
+  } else if (n1) {
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, max_wg / n_slab_slices);
+    for (uint32_t off = 0; off < n1; off += per) {
+      const uint32_t m = std::min<uint32_t>(per, n1 - off);
       ngd_launch_fixup(e->st, e->g, e->sc, e->PA, e->SM, nullptr, e->d_fixlist + off, m, 0, s_hi, sites_per_slice, n_slab_slices, 1,
                        e->slab_boot);
     }
@@ -1074,7 +1342,7 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   float ms = 0;
   hipEventElapsedTime(&ms, t0, t1);
   e->fix_info.ms += ms;
-  e->fix_info.recomputed += n;
+  e->fix_info.recomputed += all ? e->n_owned_pairs : n;
   if (patched) *patched = true;
   return NGD_OK;
 }
@@ -1858,6 +2126,17 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
       break;
     case NGD_OPT_FIXUP_WORK: e->opt_fix_work = value; break;
+    case NGD_OPT_STAGE_PIECE_MIB:
+    case NGD_OPT_STAGE_RING:
+      if (e->pin_sites) return fail(NGD_E_INVALID, "ngd_set_option: the staging ring exists already (set before the first ngd_stage_acquire)");
+      if (option == NGD_OPT_STAGE_RING) {
+        if (value < 2 || value > ngd_engine::RING) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_STAGE_RING is 2 .. 8");
+        e->opt_stage_ring = value;
+      } else {
+        if (value < 1 || value > 1024) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_STAGE_PIECE_MIB is 1 .. 1024");
+        e->opt_stage_piece_mib = value;
+      }
+      break;
     case NGD_OPT_DEBUG_FORGE_JOB: {  // tests only: the first block of the MFMA job list gets another shape
       if (e->kernel != NGD_KERNEL_MFMA || !e->d_jobs) return fail(NGD_E_INVALID, "ngd_set_option: no MFMA job list");
       HIPCHK(hipSetDevice(e->device));

@@ -22,8 +22,8 @@
 // 64-byte sector of the fragment-major image (8 x the bytes of a streaming read: ~400 B per pair-site) -- for pairs that
 // are alone in their neighbourhood.  k_fixup_tile: nearly identical individuals come in clusters, so a 16 x 16 tile of
 // individuals that holds several noted pairs is recomputed whole, coalesced (below).  The engine groups the noted pairs by
-// tile on the host and bounds the pass by the work it would be (ngd_internal.h NGD_FIX_WORK): beyond it the sums stay
-// as the MFMA pass left them (ngd_last_fixup() reports it).
+// tile on the host and recomputes every one of them in launches of bounded size (engine.hip fixup_pass; a caller-set
+// budget, NGD_OPT_FIXUP_WORK, is the only way to have pairs left as the MFMA pass computed them).
 #include "ngd_internal.h"
 
 namespace {

@@ -33,6 +33,7 @@
 //    device, except host when genotypes are called so that calls are decided by glibc).
 #include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -84,7 +85,32 @@ struct Pars {  // the reference's `params`, ngsDist.hpp:11-44
   bool single_image = false;     // --single_image
   bool two_images = false;       // --two_images
   int prep = 0;  // 0 auto (device unless genotypes are called), 1 host, 2 device
+  unsigned stage_piece = 0, stage_ring = 0, stage_grain = 2, stage_drop = 1;  // --stage (0: the engine's defaults)
 };
+
+// --verbose 2: where the wall time of a run goes, as one line of name=seconds pairs at the end of the run (stderr; the
+// reference prints nothing comparable).  A mark closes the phase that ran since the previous mark.
+struct PhaseLog {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  std::vector<std::pair<std::string, double>> phases;
+  std::mutex mu;  // (--n_gpus: every device's thread loads its own ranges)
+  void mark(const char *name) {
+    std::lock_guard<std::mutex> lk(mu);
+    const auto t = std::chrono::steady_clock::now();
+    phases.emplace_back(name, std::chrono::duration<double>(t - last).count());
+    last = t;
+  }
+  void add(const char *name, double secs) {  // a component measured elsewhere (not on the timeline)
+    std::lock_guard<std::mutex> lk(mu);
+    phases.emplace_back(name, secs);
+  }
+  void print() const {
+    fprintf(stderr, "> phases [s]:");
+    for (auto &ph : phases) fprintf(stderr, " %s=%.4f", ph.first.c_str(), ph.second);
+    fprintf(stderr, " total_since_main=%.4f\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+};
+static PhaseLog g_phases;
 
 // error(), gen_func.cpp:12-18: message, perror, exit(-1)
 [[noreturn]] static void die(const char *func, const char *msg) {
@@ -154,6 +180,7 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
                                  {"device", required_argument, nullptr, 1002},
                                  {"kernel", required_argument, nullptr, 1003},
                                  {"prep", required_argument, nullptr, 1004},
+                                 {"stage", required_argument, nullptr, 1009},
                                  {nullptr, 0, nullptr, 0}};
   p.seed = (unsigned)time(nullptr);  // parse_args.cpp:35
   int c;
@@ -185,6 +212,10 @@ static void parse_cmd_args(Pars &p, int argc, char **argv) {
       case 1001: p.n_gpus = atoi(optarg); break;
       case 1005: p.same_device = true; break;
       case 1006: p.max_device_bytes = strtoull(optarg, nullptr, 10); break;
+      case 1009:  // --stage piece_MiB,ring[,copy share MiB[,drop pages 0|1]]: the load pipeline's geometry (measurement)
+        if (sscanf(optarg, "%u,%u,%u,%u", &p.stage_piece, &p.stage_ring, &p.stage_grain, &p.stage_drop) < 2)
+          die(__FUNCTION__, "--stage takes piece_MiB,ring[,share_MiB[,drop]]");
+        break;
       case 1007: p.single_image = true; break;
       case 1008: p.two_images = true; break;
       case 1002: p.device = atoi(optarg); break;
@@ -678,9 +709,9 @@ Loader::Loader(const Pars &pars, uint64_t first_site) : p(pars) {
 void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
   const uint64_t n_ind = p.n_ind, n_sites = n_part;
   const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_sites, (64ull << 20) / (n_ind * 24)));
-  std::vector<double> buf(chunk * n_ind * 3);
   bool in_logscale = p.in_logscale;
   const bool device_prep = p.in_bin && (p.prep == 2 || (p.prep == 0 && !p.call_geno));
+  std::vector<double> buf(device_prep ? 0 : chunk * n_ind * 3);
   const unsigned n_io = std::min(16u, std::max(4u, p.n_threads));
   auto read_exact = [&](double *dst, uint64_t bytes) {
     if (raw_fd >= 0) {
@@ -709,7 +740,43 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
     }
   };
   if (p.in_bin && device_prep) {
-    // read straight into the engine's pinned buffers; copy + preparation kernel overlap the next read
+    // Straight into the engine's ring of pinned buffers; the copies to the device and the preparation kernel overlap the
+    // filling of the next buffers.  A regular file is MAPPED and its pages copied by a few kept threads: [measured, round
+    // 6, tools/host_read_pipeline, 8.6 GB in the page cache / in tmpfs] pread() on 16 threads moves 116 GB/s alone but
+    // 27-47 GB/s while the copy engine reads host memory beside it; memcpy() out of a mapping 55-57 GB/s = the link's
+    // 57.6 (first touch of the mapping's pages included).  Handing the mapping itself to the copy engine (no host copy at
+    // all) works but pins pages at 16-50 GB/s, and is not used.  (A file truncated by someone else during the run is a
+    // SIGBUS here, where pread would have reported a premature EOF.)
+    // The pages a thread has copied it takes out of the page table again at once (MADV_DONTNEED on a shared file mapping
+    // drops the translations, nothing else): left to one munmap() at the end -- or to the kernel at exit -- the 6 million
+    // 4-KB translations of 24 GB cost 0.3-0.5 s of ONE core ([measured] cfg 3: load 0.89 s, the copies themselves 0.50 s);
+    // a window mapped and unmapped per piece instead makes the copies three times slower (0.72-1.6 s).
+    const char *map = nullptr;
+    void *map_base = nullptr;
+    uint64_t map_len = 0;
+    const uint64_t pg = (uint64_t)sysconf(_SC_PAGESIZE);
+    if (raw_fd >= 0) {
+      if (raw_off + n_sites * n_ind * 24 > raw_size) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
+      const uint64_t lo = raw_off / pg * pg;
+      map_len = raw_off + n_sites * n_ind * 24 - lo;
+      void *m = mmap(nullptr, map_len, PROT_READ, MAP_SHARED, raw_fd, (off_t)lo);
+      if (m != MAP_FAILED) { map_base = m; map = (const char *)m - lo; }  // (map + file offset = that byte; else: pread as before)
+    }
+    const bool mapped = map != nullptr;
+    std::unique_ptr<TextPool> pool;
+    if (mapped) pool.reset(new TextPool(n_io));
+    auto copy_mapped = [&](double *dst, uint64_t bytes) {
+      const uint64_t grain = (uint64_t)std::max(1u, p.stage_grain) << 20, n_g = (bytes + grain - 1) / grain;
+      const char *src = map + raw_off;
+      pool->run(n_g, [&](uint64_t g0, uint64_t g1) {
+        const uint64_t b0 = g0 * grain, b1 = std::min(bytes, g1 * grain);
+        memcpy((char *)dst + b0, src + b0, b1 - b0);
+        // whole pages inside [b0, b1): a page shared with a neighbouring share stays (its owner may not have read it yet)
+        const uint64_t a0 = ((uint64_t)(uintptr_t)(src + b0) + pg - 1) / pg * pg, a1 = (uint64_t)(uintptr_t)(src + b1) / pg * pg;
+        if (a1 > a0 && p.stage_drop) madvise((void *)(uintptr_t)a0, a1 - a0, MADV_DONTNEED);
+      });
+      raw_off += bytes;
+    };
     ngd_prep pr;
     pr.in_logscale = in_logscale; pr.call_geno = p.call_geno; pr.N_thresh = p.N_thresh; pr.call_thresh = p.call_thresh;
     double t_acq = 0, t_read = 0, t_sub = 0;
@@ -724,7 +791,8 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
       if (rc) die_engine("ngd_stage_acquire", rc);
       const uint64_t n = std::min(cap, n_sites - s0);
       auto t1 = now();
-      read_exact(pin, n * n_ind * 24);
+      if (mapped) copy_mapped(pin, n * n_ind * 24);
+      else read_exact(pin, n * n_ind * 24);
       auto t2 = now();
       t_acq += secs(t0, t1); t_read += secs(t1, t2);
       auto t3 = now();
@@ -735,7 +803,15 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
     }
     if (p.verbose >= 2)
       fprintf(stderr, "> staged load: waiting for a free pinned buffer %.3f s, reading %.3f s (%s), submitting %.3f s\n", t_acq,
-              t_read, raw_fd >= 0 ? "pread on several threads" : "gzread", t_sub);
+              t_read, mapped ? "memcpy out of mapped windows of the file, on several threads" : "gzread", t_sub);
+    if (map_base) {
+      const auto tj = now();
+      munmap(map_base, map_len);
+      g_phases.add("of_load_unmap_tail", secs(tj, now()));
+    }
+    g_phases.add("of_load_wait_buffer", t_acq);
+    g_phases.add("of_load_read", t_read);
+    g_phases.add("of_load_submit", t_sub);
   } else if (p.in_bin) {
     for (uint64_t s0 = 0; s0 < n_sites; s0 += chunk) {
       const uint64_t n = std::min(chunk, n_sites - s0);
@@ -889,7 +965,11 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
               "reader thread (inflate + line split of the next group) %.3f s\n", t_first, t_work, t_up, t_join);
   }
   done += n_part;
-  eng.commit();
+  {
+    const auto t_c = std::chrono::steady_clock::now();
+    eng.commit();
+    g_phases.add("of_load_commit", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c).count());
+  }
 }
 
 void Loader::finish(bool check_eof) {
@@ -981,6 +1061,7 @@ int main(int argc, char **argv) {
     if (pos.size() != p.n_sites || n_fields < 2) die(__FUNCTION__, "invalid POS file!");
   }
 
+  g_phases.mark("args_labels");
   // devices: --n_gpus of them, the site axis split over them
   int n_dev = ngd_device_count();
   if (n_dev < 1) die(__FUNCTION__, "no HIP device found (this program has no CPU path)");
@@ -999,6 +1080,8 @@ int main(int argc, char **argv) {
     cfg.single_image = p.single_image ? 2 : p.two_images ? 3 : 0;
     int rc = ngd_create(&cfg, &eng.h);
     if (rc) die_engine("ngd_create", rc);
+    if (p.stage_piece && (rc = ngd_set_option(eng.h, NGD_OPT_STAGE_PIECE_MIB, p.stage_piece))) die_engine("ngd_set_option", rc);
+    if (p.stage_ring && (rc = ngd_set_option(eng.h, NGD_OPT_STAGE_RING, p.stage_ring))) die_engine("ngd_set_option", rc);
   };
 
   // Does the data set fit ONE device?  Resident bytes per site: both operand images (one on the EM path, the
@@ -1019,6 +1102,7 @@ int main(int argc, char **argv) {
   const uint64_t fixed = n_slabs * n_pad * n_pad * 8 + n_comb * 64 + (512ull << 20);
   uint64_t dev_free = 0, dev_total = 0;
   if (ngd_device_memory(p.device, &dev_free, &dev_total)) die_engine("ngd_device_memory", -1);
+  g_phases.mark("first_hip_calls");
   if (p.same_device) dev_free /= (uint64_t)p.n_gpus;  // the rehearsal's ranges share one device
   const uint64_t budget = p.max_device_bytes ? p.max_device_bytes : dev_free / 100 * 85;
   const bool in_parts = p.n_gpus > 1 || fixed + per_site * p.n_sites > budget;
@@ -1223,6 +1307,7 @@ int main(int argc, char **argv) {
   } else {
   Engine eng;
   make_engine(eng, p.n_sites, 0);
+  g_phases.mark("create");
   if (p.verbose >= 1) fprintf(stderr, "==> Reading genotype data\n");
   const auto t_load0 = std::chrono::steady_clock::now();
   {
@@ -1231,6 +1316,7 @@ int main(int argc, char **argv) {
     L.finish();
   }
   const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load0).count();
+  g_phases.mark("load");
   if (p.verbose >= 2)
     fprintf(stderr, "> read + prepare + upload: %.3f s (%.2f GB of prepared input resident on the device)\n", t_load,
             (double)p.n_ind * p.n_sites * 24 / 1e9);
@@ -1302,11 +1388,18 @@ int main(int argc, char **argv) {
            rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks);
     }
   }
+  g_phases.mark("matrices");
   }
+  g_phases.mark("destroy");
   fclose(out_fh);
   if (p.verbose >= 2)
     fprintf(stderr, "> distances: %.3f s for %lu matri%s of %lu pairs; formatting + writing them: %.3f s\n", t_compute,
             p.n_boot_rep + 1, p.n_boot_rep ? "ces" : "x", n_comb, t_write);
+  if (p.verbose >= 2) {
+    g_phases.add("of_matrices_distances", t_compute);
+    g_phases.add("of_matrices_format_write", t_write);
+    g_phases.print();
+  }
   if (p.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
   if (p.verbose >= 1) fprintf(stderr, "Done!\n");
   return 0;

@@ -193,15 +193,14 @@ void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *
 // p recovered out of the image T and the side array SM[site][individual] = min(p0, p2).
 #define NGD_FIX_MEAN 1e-6  // flag a pair whose sum is below this x the sites its matrix visits (error bound: 4e-17 per site)
 #define NGD_FIX_CAP 4096u  // pairs (or tiles) recomputed per LAUNCH of the fix-up kernels (the size of their scratch)
-// The reductions note up to NGD_FIX_LIST pairs (ngd_engine::fix_cap: the capacity of the list); the pass then recomputes
-// them if that is at most NGD_FIX_WORK pair-sites' worth of work -- a pair recomputed alone counts its sites once
-// ([measured] 1.25e10 pair-sites/s: ~400 bytes of 64-byte sectors per pair-site), a 16 x 16 tile of pairs recomputed
-// whole counts them NGD_FIX_TILE_COST times (2.9e9 tile-sites/s) however many of its 256 pairs are noted: 4.1e9 are
-// ~0.33 s -- 4096 scattered pairs, or 950 tiles (a cluster of ~700 copies of one individual), at 1e6 sites.  Beyond
-// either bound the sums of the one-image pass stay (a LARGE data set of clones; ngd_last_fixup() says so).  A small data
-// set may have every pair recomputed: identical called genotypes over a handful of sites are thousands of sums of exactly
-// 0, all noted (0 may be a cancelled 1e-20), and they must not crowd out the few pairs that need the pass.
-#define NGD_FIX_WORK 4096000000ull
+// The reductions note up to NGD_FIX_LIST pairs (ngd_engine::fix_cap: the capacity of the list) and the pass recomputes
+// every one of them (more than the list holds: every pair of the engine, tile by tile).  Its cost in pair-sites of work --
+// a pair recomputed alone counts its sites once ([measured] 1.25e10 pair-sites/s: ~400 bytes of 64-byte sectors per
+// pair-site), a 16 x 16 tile of pairs recomputed whole counts them NGD_FIX_TILE_COST times (2.9e9 tile-sites/s) however
+// many of its 256 pairs are noted -- only matters to a caller that sets a budget (NGD_OPT_FIXUP_WORK; rounds 4-5 had a
+// built-in one of 4.1e9, ~0.33 s, beyond which NO noted pair was recomputed: removed in round 6).  A small data set may
+// have every pair recomputed: identical called genotypes over a handful of sites are thousands of sums of exactly 0, all
+// noted (0 may be a cancelled 1e-20).
 #define NGD_FIX_LIST (1u << 20)
 #define NGD_FIX_TILE_COST_X10 43u  // (4.3)
 struct ngd_fix_flags {     // what the reduction kernels need to note the pairs that want the fix-up

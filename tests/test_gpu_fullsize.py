@@ -144,6 +144,35 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         assert np.array_equal(sp, s_perm)
 
 
+def test_one_image_engine_recomputes_a_large_data_set_of_clones_whatever_it_costs():
+    """1400 copies of one individual x 250 000 sites: 979 300 noted pairs in 3916 tiles = 4.2e9 pair-sites of recomputation --
+    above the 4.1e9 at which the engines of rounds 4-5 gave up on ALL of them and returned the one-image sums (absolute
+    error 4e-17 per site, i.e. 1e-3 relative on these sums of ~1e-8 per site).  The default engine now recomputes every one:
+    1e-9 relative against the two-image engine on every pair and against the oracle on the pairs of 12 individuals."""
+    n_ind, n_sites, eps, chunk = 1400, 250_000, 1e-9, 25_000
+    sub = np.array([0, 1, 15, 16, 17, 200, 640, 641, 900, 1398, 1399, 777])
+    keep = []
+    with N().Engine(n_ind, n_sites, kernel="mfma") as e1, N().Engine(n_ind, n_sites, kernel="mfma", single_image=3) as e2:
+        assert e1.image_mode() == (2, True) and e2.image_mode()[0] == 3
+        rng = np.random.default_rng(11)
+        for s0 in range(0, n_sites, chunk):
+            g = rng.integers(0, 3, size=chunk)
+            p = eps * (1 + rng.random((chunk, n_ind, 3)))  # site-major, as the file has it (read_data.cpp:28-31)
+            p[np.arange(chunk), :, g] = 0
+            p[np.arange(chunk), :, g] = 1 - p.sum(axis=2)
+            e1.upload_sites(p, s0)
+            e2.upload_sites(p, s0)
+            keep.append(np.ascontiguousarray(p[:, sub, :].transpose(1, 0, 2)))
+        s1, c1 = e1.commit().run()
+        f = e1.fixup()
+        s2, c2 = e2.commit().run()
+    assert f["flagged"] == f["recomputed"] == N().n_pairs(n_ind) and f["skipped"] == 0
+    assert np.array_equal(c1, c2) and rel(s1, s2) < RTOL
+    so, co = O.all_pairs(np.concatenate(keep, axis=1), n_threads=16)
+    idx = [N()._lib.load().ngd_pair_index(n_ind, int(min(a, b)), int(max(a, b))) for k, a in enumerate(sub) for b in sub[k + 1:]]
+    assert rel(s1[idx], so) < RTOL
+
+
 def test_cfg4_em_forms_agree_on_every_pair():
     """configs[3] shape (n_ind=1000, EM, JC69) on 20 000 sites, every pair: the table-driven kernel and the per-pair
     fast form vs the form whose iterates are bit-identical to emOptim2.cpp's; plus the oracle on a few pairs."""

@@ -591,6 +591,36 @@ def clones(n_ind, n_sites, eps, seed=5, n_free=0, hom_only=False):
     return p
 
 
+@pytest.mark.parametrize("pairwise_del,n_rep", [(False, 0), (True, 3)])
+def test_congruent_single_image_more_noted_pairs_than_the_list_holds(pairwise_del, n_rep):
+    """More than 2^20 pairs noted at once (1500 copies of one individual: 1 124 250 pairs): the list of noted pairs
+    overflows, WHICH pairs were noted is then unknown, and the pass recomputes every pair of the engine tile by tile -- the
+    whole matrix in gen_dist()'s own arithmetic (ngsDist.cpp:351-353).  Rounds 4-5 recomputed none of them.  1e-9 relative
+    against the oracle on every pair: a plain pass, and replicates from per-block partial results (many slab slices x
+    thousands of tiles: the launches are cut to 2^22 workgroups)."""
+    n_ind, n_sites, B = 1500, 48, 8
+    p = clones(n_ind, n_sites, 1e-10)
+    if pairwise_del:
+        miss = np.random.default_rng(3).random((n_ind, n_sites)) < 0.1
+        p[miss] = 1.0 / 3
+    so, co = O.all_pairs(p, pairwise_del=pairwise_del, n_threads=16)
+    with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, kernel="mfma") as e:  # auto: ONE image above 384 individuals
+        assert e.image_mode() == (2, True)
+        s, c = e.upload_ind_major(p).commit().run()
+        f = e.fixup()
+        assert f["flagged"] > 2 ** 20 and f["skipped"] == 0 and f["recomputed"] == N().n_pairs(n_ind)
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        if n_rep:
+            e.set_option("boot_partials", 2)
+            maps = np.stack([N().Taus(40 + r).block_map(n_sites // B) for r in range(n_rep)])
+            S, Cn = e.run_batch(maps, B)
+            assert e.fixup()["skipped"] == 0
+            for r in range(n_rep):
+                sb, cb = O.all_pairs(p, pairwise_del=pairwise_del, site_src=O.boot_site_src(maps[r], B), n_threads=16)
+                ok = cb > 0  # (a pair without a valid site in the replicate: 0 / 0 on both sides)
+                assert np.array_equal(Cn[r], cb) and rel_err(S[r][ok], sb[ok]) < RTOL, r
+
+
 @pytest.mark.parametrize("avg_nuc_dist", [False, True])
 @pytest.mark.parametrize("eps", [1e-9, 1e-13, 1e-22])
 def test_congruent_single_image_recomputes_nearly_identical_pairs(avg_nuc_dist, eps):
@@ -665,12 +695,12 @@ def test_congruent_single_image_fixup_ignores_pairs_without_valid_sites(n_sites,
 
 
 def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
-    """The fix-up pass has a budget (4.1e9 pair-sites of recomputation: ngd_internal.h NGD_FIX_WORK; NGD_OPT_FIXUP_WORK here, so
-    that the test does not need the 1200 x 400 000 copies the default takes): above it nothing is recomputed, the sums keep the
-    one-image arithmetic's absolute bound of 4e-17 per site (seven digits below the last one %.10f prints), and
-    ngd_last_fixup() says so.  Below it a data set of copies is recomputed whole -- tile by tile (clusters: 16 x 16 pairs at a
-    time, fixup.hip k_fixup_tile) and pair by pair (tiles that hold fewer than five noted pairs), 1e-9 relative either way.  A
-    symmetric matrix that is not one of the reference's has no fix-up pass at all."""
+    """The fix-up pass recomputes EVERY noted pair (round 6: no built-in budget; rounds 4-5 left all of them alone above 4.1e9
+    pair-sites of work).  Only a caller that SETS a budget (NGD_OPT_FIXUP_WORK) gets the old behaviour: above it nothing is
+    recomputed, the sums keep the one-image arithmetic's absolute bound of 4e-17 per site (seven digits below the last one
+    %.10f prints), and ngd_last_fixup() says so.  Without one a data set of copies is recomputed whole -- tile by tile
+    (clusters: 16 x 16 pairs at a time, fixup.hip k_fixup_tile) and pair by pair (tiles that hold fewer than five noted
+    pairs), 1e-9 relative either way.  A symmetric matrix that is not one of the reference's has no fix-up pass at all."""
     n_ind, n_sites = 100, 3000
     p = clones(n_ind, n_sites, 1e-9)
     so, co = O.all_pairs(p, n_threads=8)
@@ -682,7 +712,7 @@ def test_congruent_single_image_leaves_a_data_set_of_clones_alone():
         assert f["flagged"] == f["skipped"] == N().n_pairs(n_ind) and f["recomputed"] == 0
         assert np.array_equal(c1, co) and np.max(np.abs(s1 - so)) < 4e-17 * n_sites
         assert np.array_equal(np.round(s1 / n_sites, 10), np.round(so / n_sites, 10))
-        e.set_option("fixup_work", 0)  # the default budget: all 4950 pairs, 28 tiles
+        e.set_option("fixup_work", 0)  # the default, no budget: all 4950 pairs, 28 tiles
         s1, c1 = e.run()
         f = e.fixup()
     assert f["flagged"] == f["recomputed"] == N().n_pairs(n_ind) and f["skipped"] == 0
