@@ -45,6 +45,7 @@ FLOPS_PER_PAIR_SITE = 6.0   # tiled model: 3 FP64 FMA per pair-site (P . Q^T, K 
 PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (SURVEY 8d hardware constants)
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 # EM path: the per-pair algorithm's work (round 1's kernel), for comparison with what the table kernel executes
+MEAN_EM_STEPS = 11.7  # EM steps per pair-site until emOptim2.cpp:127 stops, mean on the synthetic data (3 ... 50)
 EMFAST_OPS_PER_PAIR_SITE = 272.0  # k_accum_em<fast>: SQ_THREAD_CYCLES_VALU per pair-site, profiles/r01_cfg4_em_pmc.md
 
 WORKLOADS = {
@@ -124,6 +125,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)  # the first two launches after the fill run at a lower clock
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="auto", choices=["auto", "stream", "mfma", "em_table", "em_fast", "em_faithful"])
+    ap.add_argument("--host_results", action="store_true", help="N = 1: the engine writes the job's sums straight into pinned host "
+                    "memory (its reduction kernels' stores cross the link) instead of device memory + a copy")
     ap.add_argument("--n_sites", type=int, default=0, help="override the workload's n_sites (not a valid bench line)")
     ap.add_argument("--n_boot", type=int, default=-1, help="override the workload's --n_boot_rep (bootstrap workloads)")
     ap.add_argument("--block", type=int, default=0, help="override the workload's --boot_block_size (bootstrap workloads)")
@@ -254,12 +257,26 @@ def main():
         # the node it found, beside the RCCL version -- one "rccl_preflight {...}" line on rank 0's stderr
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from rccl_preflight import preflight
+        pf_err = None
         try:
             preflight(dist, dev, args.backend, n_mat * n_pairs, n_pairs if by_reps else 0, repeats=3)
-        except Exception as exc:  # (a collective that returns WRONG data is a SystemExit and ends the run; anything else --
-            # an unknown attribute of this torch build, say -- must not cost the run its bench line)
-            sys.stderr.write("rccl_preflight: rank %d: %r (the run goes on)\n" % (rank, exc))
+        except Exception as exc:  # (a collective that returns WRONG data is a SystemExit on EVERY rank and ends the run)
+            pf_err = exc
+        # Anything else -- an unknown attribute of this torch build, say -- must not cost the run its bench line, but a rank
+        # that stopped partway through the preflight's collectives is out of step with the others: all ranks agree (MAX of
+        # their flags) and, if any of them failed, all of them start over from a barrier instead of entering the job's
+        # collectives one call apart.
+        pf_flag = torch.tensor([1.0 if pf_err is not None else 0.0], dtype=torch.float64,
+                               device=dev if args.backend == "nccl" else "cpu")
+        try:
+            dist.all_reduce(pf_flag, op=dist.ReduceOp.MAX)
+        except Exception as exc:
+            raise SystemExit("bench.py: rank %d: the ranks are out of step after the preflight (%r; first error: %r)" % (rank, exc, pf_err))
+        if pf_err is not None:
+            sys.stderr.write("rccl_preflight: rank %d: %r (the run goes on)\n" % (rank, pf_err))
             sys.stderr.flush()
+        if pf_flag.item():
+            dist.barrier()
     n_eff = n_sites - n_sites % W["block"]
     if by_sites:
         # contiguous site ranges, whole bootstrap blocks and whole 16-site groups per rank
@@ -329,7 +346,7 @@ def main():
         # A small single-GPU job (cfg 2: 19 900 cells) has its results written straight into pinned host memory, which
         # HIP maps into the device's address space: the reduction kernel's stores cross PCIe while it runs (160 KB), and
         # the separate device-to-host copy (one more launch and one more wait per 0.3 ms job) is gone.
-        zero_copy = world == 1 and total * 8 <= (1 << 20) and not pdel
+        zero_copy = world == 1 and (total * 8 <= (1 << 20) or args.host_results) and not pdel
         if zero_copy:
             d_flat = torch.zeros(world * chunk, dtype=torch.float64).pin_memory()
             d_cflat = torch.zeros(world * chunk, dtype=torch.int64).pin_memory()
@@ -832,11 +849,17 @@ def main():
             # weights; algorithmic flops: 2 per (matrix of the padded groups of 16, pair slot, unit).  Whichever of the two
             # takes longer at its peak is the bound: HBM up to ~32 matrices, the FP64 matrix pipe above.
             mg, sg, sgl, un, ch = (spill[k] for k in ("matrix_groups", "slot_groups", "slot_groups_live", "units", "chunks"))
+            # `frac` is on USEFUL work -- the job's real matrices x real pairs -- like every other frac of this file; what the
+            # kernel ISSUES (matrices padded to groups of 16, pair slots to groups of 16 and to the wavefronts' 2 or 4 groups) is
+            # printed beside it as issued_frac.
             term_bytes = un * sgl * 16 * 8
-            c_bytes = term_bytes * np.ceil(mg / 8) + 2 * 8 * mg * sg * 256 * ch + (un + 4 * ch) * mg * 16 * 8
-            c_flops = 2.0 * (16 * mg) * (16 * sg) * un
+            i_bytes = term_bytes * np.ceil(mg / 8) + 2 * 8 * mg * sg * 256 * ch + (un + 4 * ch) * mg * 16 * 8
+            i_flops = 2.0 * (16 * mg) * (16 * sg) * un
+            c_bytes = un * n_pairs * 8 * np.ceil(n_mat / 128) + 2 * 8 * n_mat * n_pairs * ch + (un + 4 * ch) * n_mat * 8
+            c_flops = 2.0 * n_mat * n_pairs * un
             t_c = spill["ms_contract"] * 1e-3
             c_hbm, c_mf = c_bytes / t_c / 1e9, c_flops / t_c / 1e12
+            i_hbm, i_mf = i_bytes / t_c / 1e9, i_flops / t_c / 1e12
             by_hbm = c_hbm / PEAK_HBM_GBS >= c_mf / PEAK_FP64_TFLOPS
             roof["ms_per_job"] = spill["ms_terms"]
             roof["launches_per_job"] = ch
@@ -851,20 +874,43 @@ def main():
                 "achieved": c_hbm if by_hbm else c_mf, "peak": PEAK_HBM_GBS if by_hbm else PEAK_FP64_TFLOPS,
                 "unit": "GB/s" if by_hbm else "TFLOP/s",
                 "frac": c_hbm / PEAK_HBM_GBS if by_hbm else c_mf / PEAK_FP64_TFLOPS,
-                "hbm": {"achieved": c_hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": c_hbm / PEAK_HBM_GBS},
-                "mfma": {"achieved": c_mf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": c_mf / PEAK_FP64_TFLOPS},
+                "issued_frac": i_hbm / PEAK_HBM_GBS if by_hbm else i_mf / PEAK_FP64_TFLOPS,
+                "hbm": {"achieved": c_hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": c_hbm / PEAK_HBM_GBS,
+                        "issued_frac": i_hbm / PEAK_HBM_GBS},
+                "mfma": {"achieved": c_mf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": c_mf / PEAK_FP64_TFLOPS,
+                         "issued_frac": i_mf / PEAK_FP64_TFLOPS},
                 "ms_per_job": spill["ms_contract"], "ms_per_launch": spill["ms_contract"] / spill["contract_launches"],
                 "traffic": None,
-                "algorithmic": "%.4g B per job: %.4g B of terms (%d units x %d live pair slots x 8 B) read once per 128 matrices, "
-                               "the running sums (%d x %d x 8 B) read and written once per chunk (%d), the weights; %.4g flop = "
-                               "2 x %d matrices (padded to 16s) x %d pair slots x %d units"
-                               % (c_bytes, term_bytes, un, sgl * 16, 16 * mg, 16 * sg, ch, c_flops, 16 * mg, 16 * sg, un)}
+                "algorithmic": "USEFUL work: %.4g B per job (%d units x %d pairs x 8 B of terms read once per 128 matrices, the "
+                               "running sums of %d matrices x %d pairs read and written once per chunk (%d), the weights); %.4g "
+                               "flop = 2 x %d matrices x %d pairs x %d units.  ISSUED (issued_frac): %.4g B, %.4g flop = 2 x %d "
+                               "matrices (padded to 16s) x %d pair slots x %d units"
+                               % (c_bytes, un, n_pairs, n_mat, n_pairs, ch, c_flops, n_mat, n_pairs, un, i_bytes, i_flops,
+                                  16 * mg, 16 * sg, un)}
         if kernel == "em_table":
             tile_sites, rounds = eng.em_work()
             roof["table_rounds_per_tile_site"] = rounds / max(1, tile_sites)
+            # What the closed form NEEDS per pair-site on this data, so that the ~93 lane-instructions the kernel executes have
+            # a denominator (emOptim2.cpp:112-135 in the closed form of DESIGN.md section 3 K2): the search for the step T at
+            # which the reference's rule stops (:127) is one compare + one count per step and cannot skip steps (the rule takes
+            # the FIRST step that satisfies it, and R_t(i1) R_t(i2) is not monotone in t in general); the site's term is three
+            # products and their sum against the per-individual g_T (ngsDist.cpp:351-353); the tables belong to ONE individual
+            # and need building once per individual and site (the kernel rebuilds them per 64 x 64 tile of pairs: n_ind / 64
+            # times), ~35 lane-instructions per step (three powers, their sum, R_t with one division, f_t, g_t = score . f_t, Q_t).
+            rounds_mean = rounds / max(1, tile_sites)
+            alg = 2 * MEAN_EM_STEPS + 4 + 35.0 * 16 * rounds_mean * n_ind / n_pairs
+            roof["algorithmic_lane_instructions_per_pair_site"] = alg
+            roof["algorithmic_frac"] = alg * ps_launch / t_acc / lane_peak
+            roof["algorithmic_model"] = (
+                "2 x %.1f (one compare + one count per EM step until the rule of emOptim2.cpp:127 stops; mean steps per pair-site "
+                "on this data) + 4 (the three products and the sum of ngsDist.cpp:351-353 against g_T) + %.2f (tables of 16 steps x "
+                "%.2f rounds, ~35 lane-instructions a step, built ONCE per individual and site and shared by its %d pairs); the "
+                "kernel executes ~3 x this: it rebuilds the tables per 64 x 64 tile (%.1f tiles per individual), searches in "
+                "blocks of 8 steps, and moves thresholds and operands through LDS"
+                % (MEAN_EM_STEPS, 35.0 * 16 * rounds_mean * n_ind / n_pairs, rounds_mean, n_ind - 1, n_ind / 64.0))
         # SURVEY 8(d)'s algorithmic count of the reference's form (emOptim2.cpp:77-109: per EM step 36 mul + 37 add + 18 div
         # + 1 log, + the first lik2 and the 18-flop scoring per site), at this data set's mean of 11.7 steps per pair-site
-        ref_flop = 11.7 * (36 + 37 + 18 + 1) + (27 + 1) + 18
+        ref_flop = MEAN_EM_STEPS * (36 + 37 + 18 + 1) + (27 + 1) + 18
         roof["reference_form_model"] = {"flop_per_pair_site": ref_flop, "achieved_TFLOPs": ref_flop * ps_launch / t_acc / 1e12,
                                         "note": "what the reference's arithmetic would need at this rate; the kernel's closed "
                                                 "form and per-individual tables remove most of it (DESIGN.md section 3, K2)"}

@@ -305,6 +305,8 @@ int ngd_drop_caches(ngd_engine *e);
 #define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
                                  /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
                                  /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */
+                                 /*     Refused (NGD_E_INVALID) unless the environment has NGD_ENABLE_TEST_HOOKS=1: the       */
+                                 /*     engine's job list stays forged, every later run of it fails                           */
 int ngd_set_option(ngd_engine *e, int option, uint64_t value);
 
 int ngd_last_timing(const ngd_engine *e, ngd_timing *t);

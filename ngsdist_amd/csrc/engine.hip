@@ -2138,6 +2138,10 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       }
       break;
     case NGD_OPT_DEBUG_FORGE_JOB: {  // tests only: the first block of the MFMA job list gets another shape
+      // (an engine with a forged job list computes nothing right ever after: refused unless the process says it is a test)
+      const char *hook = getenv("NGD_ENABLE_TEST_HOOKS");
+      if (!hook || strcmp(hook, "1") != 0)
+        return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_DEBUG_FORGE_JOB is a test hook (set NGD_ENABLE_TEST_HOOKS=1)");
       if (e->kernel != NGD_KERNEL_MFMA || !e->d_jobs) return fail(NGD_E_INVALID, "ngd_set_option: no MFMA job list");
       HIPCHK(hipSetDevice(e->device));
       ngd_job j;

@@ -179,7 +179,7 @@ def test_nothing_to_fetch_after_a_failed_job():
 
 
 @pytest.mark.parametrize("form,shape", [(3, 2 | 1 << 3 | 1 << 6), (5, 1 | 2 << 3), (6, 3 | 3 << 3), (6, 2 | 1 << 3 | 1 << 6)])
-def test_a_block_shape_the_kernel_does_not_list_fails_the_run(form, shape):
+def test_a_block_shape_the_kernel_does_not_list_fails_the_run(form, shape, monkeypatch):
     """accum_mfma.hip has one code path per block shape of a form (rows x cols tiles, triangular or not); ngd_create()
     builds only listed shapes (and checks).  Should an unlisted one ever reach the kernel -- forged here through the
     test-only option NGD_OPT_DEBUG_FORGE_JOB -- the block's sums are poisoned and the run fails with NGD_E_HIP, on the
@@ -190,6 +190,12 @@ def test_a_block_shape_the_kernel_does_not_list_fails_the_run(form, shape):
     with N.Engine(n_ind, n_sites, kernel="mfma", exact_shapes=form) as e:
         e.upload_ind_major(p).commit()
         s, c = e.run()
+        monkeypatch.delenv("NGD_ENABLE_TEST_HOOKS", raising=False)
+        with pytest.raises(N.NgdError) as ei:  # a test hook: refused in a process that does not say it is a test
+            e.set_option("debug_forge_job", shape)
+        assert ei.value.code == -1  # NGD_E_INVALID
+        assert np.array_equal(e.run()[0], s)
+        monkeypatch.setenv("NGD_ENABLE_TEST_HOOKS", "1")
         e.set_option("debug_forge_job", shape)
         with pytest.raises(N.NgdError) as ei:
             e.run()

@@ -38,6 +38,14 @@ def test_two_ranks_cfg2_by_pair_tiles():
     assert out["valid"] is True and out["n_gpus"] == 2
 
 
+def test_two_ranks_one_matrix_each_by_replicates():
+    # --shard replicates, the weak-scaling split (one matrix per GPU, ONE all-gather of finished matrices: SURVEY 8e):
+    # rank 0 the full-data matrix, rank 1 a bootstrap replicate at the reference's default block size
+    out = _bench("--workload", "cfg2", "--shard", "replicates")
+    assert out["valid"] is True and out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["matrices_per_step"] == 2
+
+
 def test_two_ranks_cfg5_bootstrap_job_reduced_sites():
     # cfg 5's shape (500 individuals, 64 replicates of 1000-site blocks + the full-data matrix) on 1/10 of its sites
     out = _bench("--workload", "cfg5", "--n_sites", "50000")

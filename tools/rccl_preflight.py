@@ -65,8 +65,23 @@ def preflight(dist, dev, backend, cells_total, per_rank_gather=0, repeats=5, out
     except Exception as exc:  # the version is a nicety
         rep["rccl_version"] = "unknown (%r)" % (exc,)
     rep["env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_P2P_DISABLE",
+                                                  "NCCL_SHM_DISABLE", "NCCL_P2P_LEVEL", "NCCL_NET_GDR_LEVEL",
                                                   "RCCL_MSCCL_ENABLE", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
                                                   "MASTER_ADDR") if os.environ.get(k) is not None}
+    # HSA_ENABLE_IPC_MODE_LEGACY: "0" selects dmabuf IPC, which is what this pool's driver supports; unset or "1" and RCCL's
+    # peer-to-peer set-up fails with hipIpcGetMemHandle: invalid argument (bench.py exports 0 for the ranks it launches)
+    rep["hsa_enable_ipc_mode_legacy"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "(unset)")
+    # did the ranks reach one another directly?  Peer access between the devices of this node, as HIP reports it: without it
+    # RCCL stages every message through host memory (shared-memory transport) and the bus bandwidths below are PCIe's
+    if on_gpu:
+        try:
+            n_dev = torch.cuda.device_count()
+            me = dev.index if hasattr(dev, "index") and dev.index is not None else torch.cuda.current_device()
+            peers = [bool(torch.cuda.can_device_access_peer(me, q)) for q in range(n_dev) if q != me]
+            rep["peer_access"] = {"devices": n_dev, "peers_reachable": int(sum(peers)), "all": bool(all(peers)) if peers else None}
+            rep["host_staging_suspected"] = bool(peers) and not all(peers)
+        except Exception as exc:
+            rep["peer_access"] = "unknown (%r)" % (exc,)
     ring = (world - 1) / world
 
     def bus(nbytes, ms, factor=1.0):  # GB/s per rank under the ring model
@@ -85,8 +100,18 @@ def preflight(dist, dev, backend, cells_total, per_rank_gather=0, repeats=5, out
     rep["all_gather"] = r
     ok_ag = all(bool(torch.all(g_all[q * g_chunk:(q + 1) * g_chunk] == float(q)).item()) for q in range(world))
     rep["results_checked"] = {"reduce_scatter_sum_is_world": ok_rs, "all_gather_rows_in_rank_order": ok_ag}
-    if not (ok_rs and ok_ag):
-        raise SystemExit("rccl_preflight: rank %d: a collective returned wrong data: %s" % (rank, json.dumps(rep)))
+    # ONE verdict for all ranks (MIN over their flags): a rank that left alone would leave the others waiting in the next
+    # collective until the backend's timeout
+    flag = torch.tensor([1.0 if (ok_rs and ok_ag) else 0.0], dtype=torch.float64, device=t_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    sync()
+    rep["all_ranks_ok"] = bool(flag.item() == 1.0)
+    if not rep["all_ranks_ok"]:
+        raise SystemExit("rccl_preflight: rank %d: a collective returned wrong data on some rank (here: %s): %s"
+                         % (rank, "wrong" if not (ok_rs and ok_ag) else "right", json.dumps(rep)))
+    if on_gpu and flat.numel() * 8 >= (1 << 22) and rep["reduce_scatter"]["busbw_GBs"] is not None:
+        # (an xGMI link moves ~50 GB/s and more; a few GB/s on warm messages of several MB means staging through the host)
+        rep["busbw_suggests_host_staging"] = bool(rep["reduce_scatter"]["busbw_GBs"] < 10.0)
     if rank == 0 and out is not None:
         out.write("rccl_preflight " + json.dumps(rep) + "\n")
         out.flush()
