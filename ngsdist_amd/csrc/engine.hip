@@ -961,7 +961,10 @@ int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites
   const int b = e->pin_cur;
   rc = stage_slot(e, b);
   if (rc) return rc;
-  HIPCHK(hipEventSynchronize(e->pin_free[b]));  // the copy out of this buffer (a turn of the ring ago) is done
+  // the copy out of this buffer, a turn of the ring ago, is done -- and so is the preparation kernel that read its device
+  // twin (it follows the copy on the engine's stream, ~30 us): waited for HERE, on the host, so that the copy streams carry
+  // no wait of their own ([measured] a stream-side wait on an event costs the copy engine ~50 us of idling per copy)
+  HIPCHK(hipEventSynchronize(e->k0_done[b]));
   e->pin_lent = b;
   *host_buf = e->pin[b];
   *capacity_sites = e->pin_sites;
@@ -978,7 +981,6 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
   HIPCHK(hipSetDevice(e->device));
   const int b = e->pin_lent;
   hipStream_t cs = e->st_copy[e->n_staged++ & 1];
-  HIPCHK(hipStreamWaitEvent(cs, e->k0_done[b], 0));  // (never recorded yet: no wait)
   HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, cs));
   HIPCHK(hipEventRecord(e->pin_free[b], cs));
   HIPCHK(hipStreamWaitEvent(e->st, e->pin_free[b], 0));

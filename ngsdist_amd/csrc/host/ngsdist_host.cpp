@@ -1118,7 +1118,56 @@ int main(int argc, char **argv) {
   std::vector<double> dist(n_comb);
   std::vector<const char *> label_ptr;
   for (auto &l : labels) label_ptr.push_back(l.c_str());
-  std::vector<char> text;
+  // A matrix's text is written by a thread of its own while the next matrix is fetched, finished and formatted: two
+  // buffers ([measured, round 6] 101 matrices of 1000 individuals, 1.3 GB of text: 8.3 ms a matrix with the write inline).
+  std::vector<char> text_buf[2];
+  struct Writer {
+    FILE *fh = nullptr;
+    std::mutex m;
+    std::condition_variable cv;
+    const char *data = nullptr;
+    size_t len = 0;
+    bool quit = false, failed = false, busy = false;
+    std::thread th;
+    void start(FILE *f) {
+      fh = f;
+      th = std::thread([this]() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          cv.wait(lk, [&] { return quit || data; });
+          if (!data) return;
+          const char *d = data;
+          const size_t n = len;
+          lk.unlock();
+          const bool ok = fwrite(d, 1, n, fh) == n;
+          lk.lock();
+          if (!ok) failed = true;
+          data = nullptr;
+          busy = false;
+          cv.notify_all();
+        }
+      });
+    }
+    void wait_idle() {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return !busy; });
+    }
+    void submit(const char *d, size_t n) {  // (the caller has waited for the writer to be idle)
+      std::lock_guard<std::mutex> lk(m);
+      data = d; len = n; busy = true;
+      cv.notify_all();
+    }
+    bool finish() {  // everything handed in is written; false if a write failed
+      if (!th.joinable()) return true;
+      wait_idle();
+      { std::lock_guard<std::mutex> lk(m); quit = true; }
+      cv.notify_all();
+      th.join();
+      return !failed;
+    }
+  } writer;
+  writer.start(out_fh);
+  uint64_t n_emitted = 0;
 
   // one matrix of the output: the reference's progress lines in its order (:218-241, :281), the tail of gen_dist
   // and the print block
@@ -1150,6 +1199,7 @@ int main(int argc, char **argv) {
     if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
     // ngsDist.cpp:282-287 (join(), gen_func.cpp:479-496); rows formatted in parallel, same bytes
     const auto t_w0 = std::chrono::steady_clock::now();
+    std::vector<char> &text = text_buf[n_emitted++ & 1];  // (the writer may still be on the other one)
     if (text.empty()) text.resize(64 + p.n_ind * (p.n_ind * 16 + 64));
     int64_t need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
     if (need > (int64_t)text.size()) {
@@ -1157,7 +1207,9 @@ int main(int argc, char **argv) {
       need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
     }
     if (need < 0) die(__FUNCTION__, "cannot format the distance matrix");
-    if (fwrite(text.data(), 1, (size_t)need, out_fh) != (size_t)need) die(__FUNCTION__, "cannot write output file!");
+    writer.wait_idle();  // the previous matrix is on its way out: matrices are written in order, one at a time
+    if (writer.failed) die(__FUNCTION__, "cannot write output file!");
+    writer.submit(text.data(), (size_t)need);
     t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
   };
 
@@ -1391,6 +1443,8 @@ int main(int argc, char **argv) {
   g_phases.mark("matrices");
   }
   g_phases.mark("destroy");
+  if (!writer.finish()) die(__FUNCTION__, "cannot write output file!");
+  g_phases.mark("write_tail");
   fclose(out_fh);
   if (p.verbose >= 2)
     fprintf(stderr, "> distances: %.3f s for %lu matri%s of %lu pairs; formatting + writing them: %.3f s\n", t_compute,

@@ -99,14 +99,30 @@ static inline char *fmt_fixed10(double x, char *o) {
     if (rem > half || (rem == half && (N & 1))) N++;
   }
   const uint64_t ip = N / 10000000000ull;
-  uint64_t fp = N % 10000000000ull;
-  char tmp[24];
-  int n = 0;
-  uint64_t v = ip;
-  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-  while (n) *o++ = tmp[--n];
+  uint64_t fp = N - ip * 10000000000ull;
+  if (ip < 10) {  // (every distance but a saturated one)
+    *o++ = (char)('0' + ip);
+  } else {
+    char tmp[24];
+    int n = 0;
+    uint64_t v = ip;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *o++ = tmp[--n];
+  }
   *o++ = '.';
-  for (int d = 9; d >= 0; d--) { o[d] = (char)('0' + fp % 10); fp /= 10; }
+  // ten digits, two at a time (32-bit arithmetic: fp < 10^10 = two halves below 10^5)
+  static const char kPairs[] =
+      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960"
+      "616263646566676869707172737475767778798081828384858687888990919293949596979899";
+  const uint32_t hi = (uint32_t)(fp / 100000), lo = (uint32_t)(fp - (uint64_t)hi * 100000);
+  const uint32_t h0 = hi / 1000, h1 = hi % 1000;  // hi = h0 (2 digits) h1 (3 digits)
+  memcpy(o, kPairs + 2 * h0, 2);
+  o[2] = (char)('0' + h1 / 100);
+  memcpy(o + 3, kPairs + 2 * (h1 % 100), 2);
+  const uint32_t l0 = lo / 1000, l1 = lo % 1000;
+  memcpy(o + 5, kPairs + 2 * l0, 2);
+  o[7] = (char)('0' + l1 / 100);
+  memcpy(o + 8, kPairs + 2 * (l1 % 100), 2);
   return o + 10;
 }
 

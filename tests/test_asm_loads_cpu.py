@@ -18,7 +18,7 @@ pytestmark = pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/o
 
 @pytest.mark.parametrize("source,flags", [("accum_mfma.hip", ()), ("contract_mfma.hip", ()),
                                           # the A/B builds of the LDS form's fetch depth (shipped: 4) and of the register
-                                          # forms' rings (tools/exact_depth_sweep.sh)
+                                          # forms' rings (tools/history/r4/exact_depth_sweep.sh)
                                           ("accum_mfma.hip", ("-DNGD_LDS_PF=1",)), ("accum_mfma.hip", ("-DNGD_LDS_PF=2",)),
                                           ("accum_mfma.hip", ("-DNGD_EXACT2_DEPTH=2", "-DNGD_EXACT4_DEPTH=1"))])
 def test_no_register_is_touched_while_a_hand_issued_load_into_it_is_outstanding(source, flags):
