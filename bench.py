@@ -372,6 +372,7 @@ def main():
         # one order.
         import concurrent.futures
         tail_pool = concurrent.futures.ThreadPoolExecutor(1, initializer=lambda: torch.cuda.set_device(local_rank))
+        fin_pool = concurrent.futures.ThreadPoolExecutor(1)  # (the one call of ngd_finish_stream of a job's tail)
         tail_job = [None, None]
         step_no = [0]
         d_flat_b = [d_flat, torch.zeros_like(d_flat).pin_memory() if zero_copy else torch.zeros_like(d_flat)]
@@ -523,14 +524,36 @@ def main():
             def tail():
                 cnts = h_call1.numpy().view(np.uint64) if pdel else cnt_job
                 which = 2 if pdel else (0 if cnts is cnt_flat else 1)  # (1: --vary_jobs' other job)
-                for c, (a, b) in enumerate(chunks):
-                    if not zero_copy:
+                if not zero_copy and total >= (1 << 20):
+                    # a job of millions of cells: ONE call of ngd_finish_stream on a helper thread works the cells as the
+                    # chunks land (this thread waits for the copies' events and raises the counter): one wake-up of the
+                    # host's threads per job instead of one per chunk
+                    key = (buf, "stream", which)
+                    a_ = finish_args.get(key)
+                    if a_ is None:
+                        dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+                        sums, out = ha.numpy().reshape(-1)[:total], dist_all.reshape(-1)
+                        assert sums.flags.c_contiguous and cnts.flags.c_contiguous and out.flags.c_contiguous and cnts.size == total
+                        landed = C.c_uint64(0)
+                        a_ = finish_args[key] = (sums.ctypes.data_as(dp), cnts.ctypes.data_as(up), total, 0, int(W["evol_model"]),
+                                                 out.ctypes.data_as(dp), C.byref(landed), landed, sums, cnts, out)
+                    landed = a_[7]
+                    landed.value = 0
+                    fut = fin_pool.submit(L_abi.ngd_finish_stream, *a_[:7])
+                    for c, (a, b) in enumerate(chunks):
                         evs[c].synchronize()
-                    key = (buf, c, which)
-                    if key in finish_args:
-                        finish_chunk(key, None, None, None)
-                    else:
-                        finish_chunk(key, ha[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], dist_all[a:b].reshape(-1))
+                        landed.value = b * n_pairs
+                    if fut.result() != 0:
+                        raise RuntimeError("ngd_finish_stream failed")
+                else:
+                    for c, (a, b) in enumerate(chunks):
+                        if not zero_copy:
+                            evs[c].synchronize()
+                        key = (buf, c, which)
+                        if key in finish_args:
+                            finish_chunk(key, None, None, None)
+                        else:
+                            finish_chunk(key, ha[a:b].numpy().reshape(-1), cnts[a * n_pairs:b * n_pairs], dist_all[a:b].reshape(-1))
                 last["dist"] = dist_all[-1]
                 if args.vary_jobs:
                     sums_seen[region].append(checksum(dist_all))

@@ -358,6 +358,12 @@ int ngd_last_em_work(const ngd_engine *e, uint64_t *tile_sites, uint64_t *table_
  *   model 0: d; 1: -log(1-d); 2: -log(1-d*4/3)*3/4; 3..6: NGD_E_MODEL. */
 int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs,
                uint64_t tot_sites, uint64_t evol_model, double *dist);
+/* The same over cells that are still arriving (a job's matrices leaving the device chunk by chunk): cells [0, *landed)
+ * of sum and cnt are final; the caller -- another thread -- raises *landed, in any steps, up to n_pairs, and the call
+ * returns when every cell is finished.  One wake-up of the host threads for the whole job: the tail runs beside the
+ * copies (ngsDist.cpp:372-401 on up to millions of cells per bootstrap job). */
+int ngd_finish_stream(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites, uint64_t evol_model,
+                      double *dist, const volatile uint64_t *landed);
 
 /* The print block of one matrix, ngsDist.cpp:282-287 with join() gen_func.cpp:479-496:
  * "\n<n_ind>\n", then per individual its label and n_ind cells "\t%.10f", newline.  `dist` is

@@ -65,7 +65,7 @@ EXPORTS = [
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
     "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
-    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_fixup", "ngd_image_mode", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
+    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_fixup", "ngd_image_mode", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_finish_stream", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair", "ngd_shard_map",
     "ngd_score_congruence",
 ]
@@ -130,6 +130,7 @@ def load():
     L.ngd_last_em_work.argtypes = [vp, u64p, u64p]
     L.ngd_last_shader_clock.argtypes = [vp, dp]
     L.ngd_finish.argtypes = [dp, u64p, u64, u64, u64, dp]
+    L.ngd_finish_stream.argtypes = [dp, u64p, u64, u64, u64, dp, u64p]
     L.ngd_format_matrix.argtypes = [dp, u64, C.POINTER(C.c_char_p), C.c_char_p, u64, C.c_uint32]
     L.ngd_format_matrix.restype = C.c_int64
     L.ngd_device_memory.argtypes = [C.c_int, u64p, u64p]

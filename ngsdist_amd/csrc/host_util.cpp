@@ -3,6 +3,7 @@
 // the tail of gen_dist() (reference ngsDist.cpp:372-401) and the bootstrap block
 // draw (ngsDist.cpp:416-423 over gsl_rng_taus, seeded at :179-180).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -374,6 +375,37 @@ int ngd_finish(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_
       const uint64_t lo = k * per, hi = std::min(n_pairs, lo + per);
       if (lo < hi) finish_range(sum, cnt, lo, hi, tot_sites, evol_model, dist);
     });
+  }
+  return NGD_OK;
+}
+
+// ngd_finish() over cells that are still ARRIVING (a job's matrices coming off the device chunk by chunk): the pool is
+// woken once for the whole job and a share of cells is worked as soon as *landed says it is final, so the tail of
+// gen_dist() runs beside the copies instead of one pool wake-up per chunk ([measured, round 6] 8.1e6 cells: 1.3 ms in one
+// call, 2.7 ms in 8).  Shares are handed out in ascending order; a thread whose share has not landed yet spins on the counter.
+int ngd_finish_stream(const double *sum, const uint64_t *cnt, uint64_t n_pairs, uint64_t tot_sites, uint64_t evol_model,
+                      double *dist, const volatile uint64_t *landed) {
+  if (evol_model > 2) return NGD_E_MODEL;
+  if (!sum || !cnt || !dist || !landed) return NGD_E_INVALID;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const bool wide = n_pairs >= (1u << 19) && hw > 16;
+  const unsigned nt = wide ? std::min(64u, hw) : std::min(16u, hw);
+  const unsigned parts = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, n_pairs / 16384), 8 * nt);
+  const uint64_t per = (n_pairs + parts - 1) / parts;
+  auto share = [&](unsigned k) {
+    const uint64_t lo = k * per, hi = std::min(n_pairs, lo + per);
+    if (lo >= hi) return;
+    for (unsigned spins = 0; *landed < hi; spins++) {
+      if (spins < 4096) __builtin_ia32_pause();
+      else std::this_thread::yield();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    finish_range(sum, cnt, lo, hi, tot_sites, evol_model, dist);
+  };
+  if (nt <= 1 || parts <= 1) {
+    for (unsigned k = 0; k < parts; k++) share(k);
+  } else {
+    (wide ? host_pool_wide() : host_pool()).run(parts, share);
   }
   return NGD_OK;
 }

@@ -162,3 +162,59 @@ def test_finish_and_format_from_several_threads_at_once():
     for k in range(6):
         assert np.array_equal(out[k], want, equal_nan=True)
         assert txt[k] == want_txt
+
+
+@pytest.mark.parametrize("model", [0, 1, 2])
+def test_finish_stream_works_cells_as_they_land(model, lib):
+    """ngd_finish_stream: the tail of gen_dist() (ngsDist.cpp:372-401) over cells that arrive chunk by chunk (a bootstrap job's
+    matrices leaving the device): another thread raises the counter of landed cells; cells beyond it hold garbage until then
+    and must not be read early.  Same bits as ngd_finish() and as the oracle."""
+    import ctypes as C
+    import threading
+    import time
+    rng = np.random.default_rng(model)
+    n = 700_001
+    s_true = rng.random(n) * 0.3 * 1000
+    s_true[:6] = [0.0, 1e-300, 1000.0, 999.9999, 750.0, np.nan]
+    c = rng.integers(1, 2000, n).astype(np.uint64)
+    c[3] = 0
+    with np.errstate(all="ignore"):
+        want = O.finish(s_true, c, 0, model)
+    s = np.full(n, -7.0)  # what a buffer holds before its chunk lands
+    out = np.empty(n)
+    landed = C.c_uint64(0)
+    dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+
+    def feeder():
+        edges = [0, 1, 5000, 5001, n // 3, n // 2, n - 1, n]
+        for a, b in zip(edges[:-1], edges[1:]):
+            time.sleep(0.003)
+            s[a:b] = s_true[a:b]
+            landed.value = b
+
+    t = threading.Thread(target=feeder)
+    t.start()
+    rc = lib.ngd_finish_stream(s.ctypes.data_as(dp), c.ctypes.data_as(up), n, 0, model, out.ctypes.data_as(dp), C.byref(landed))
+    t.join()
+    assert rc == 0
+    assert np.array_equal(out.view(np.uint64), want.view(np.uint64))
+    assert lib.ngd_finish_stream(s.ctypes.data_as(dp), c.ctypes.data_as(up), n, 0, 3, out.ctypes.data_as(dp), C.byref(landed)) != 0
+
+
+def test_finish_division_is_vectorised_and_exact():
+    """d = sum / cnt is a loop of its own (host_util.cpp divide_range: counts below 2^52 converted by the exponent trick,
+    AVX2 clone where the CPU has it): the same bits as the scalar (double)cnt division for every count size and for
+    --tot_sites, ranges that start and end off the vector width."""
+    import ngsdist_amd as N
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4, 5, 63, 4097, 19_900):
+        s = rng.random(n) * 1e6 * rng.choice([1e-12, 1.0, 1e9], size=n)
+        for cmax in (2, 1 << 20, 1 << 51, (1 << 63) + 12345):
+            c = rng.integers(1, cmax, n, dtype=np.uint64)
+            if n > 2:
+                c[1] = 0
+            for tot in (0, 77):
+                with np.errstate(all="ignore"):
+                    got = N.finish(s, c, tot, 0)
+                    want = s / (np.float64(tot) if tot else c.astype(np.float64))
+                assert np.array_equal(got.view(np.uint64), np.asarray(want).view(np.uint64)), (n, cmax, tot)
