@@ -13,9 +13,10 @@
 
 struct ngd_engine {
   ngd_config cfg;
-  std::vector<double> stage[2];
+  std::vector<double> stage[3];  // (a ring, as the engine's: a buffer comes back a turn of the ring later)
   uint64_t cap = 0;
   int cur = 0, lent = -1;
+  uint64_t opt_piece_mib = 0, opt_ring = 0;
   bool committed = false;
   uint64_t seen_sites = 0;
   double checksum = 0;
@@ -70,9 +71,16 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
   if (!e || !prep || e->lent < 0 || n > e->cap || s0 + n > e->cfg.n_sites) return fail(NGD_E_INVALID, "stub: stage_submit");
   touch(e, e->stage[e->lent].data(), n * e->cfg.n_ind * 3);
   std::fill(e->stage[e->lent].begin(), e->stage[e->lent].end(), -1.0);
-  e->cur ^= 1;
+  e->cur = (e->cur + 1) % 3;
   e->lent = -1;
   e->seen_sites += n;
+  return NGD_OK;
+}
+int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
+  if (!e) return fail(NGD_E_INVALID, "stub: set_option");
+  if (option == NGD_OPT_STAGE_PIECE_MIB) e->opt_piece_mib = value;
+  else if (option == NGD_OPT_STAGE_RING) e->opt_ring = value;
+  else return fail(NGD_E_INVALID, "stub: unknown option");
   return NGD_OK;
 }
 int ngd_commit(ngd_engine *e) {
