@@ -102,8 +102,11 @@ typedef struct ngd_config {
                          /*     min(p0, p2) beside the image, 8 more bytes per individual and site: 32 in all), so 1e-9    */
                          /*     relative holds at any distance, unconditionally: every qualifying pair is recomputed,      */
                          /*     however many there are (clusters of copies tile by tile, 60 times cheaper than pair by     */
-                         /*     pair; more than 2^20 of them: every pair of the matrix, ~0.8 s at 1000 x 1e6 -- a data set  */
-                         /*     of clones).  ngd_last_fixup() reports what a run recomputed.  Only a caller that SETS a     */
+                         /*     pair; where the tiles would cost more than the whole matrix in the two-image arithmetic --  */
+                         /*     a data set of clones -- one more pass over scratch images formed a range of sites at a time */
+                         /*     does it: ~70 ms at 1000 x 1e6 whatever the data; replicates from per-block partial results  */
+                         /*     go tile by tile at any count, up to ~0.8 s at that size).  ngd_last_fixup() reports what a  */
+                         /*     run recomputed.  Only a caller that SETS a                                                  */
                          /*     budget (NGD_OPT_FIXUP_WORK) can have pairs left at the absolute bound.                     */
                          /*     Any other symmetric matrix: no fix-up.  NGD_E_INVALID for an asymmetric matrix.            */
                          /* 1 = p resident, q formed for a range of sites at a time before the launch that reads it: the   */
@@ -322,6 +325,9 @@ int ngd_image_mode(const ngd_engine *e, int *fixup);
 typedef struct ngd_fixup_info {
   uint64_t flagged, recomputed, skipped;
   double ms;
+  uint64_t by_pass; /* recomputations that went the whole-matrix way: so many noted pairs that ONE more pass in the    */
+                    /* two-image arithmetic over scratch images (a pass and a half: ~70 ms at 1000 x 1e6) was cheaper  */
+                    /* than their tiles -- a data set of clones; the noted pairs take its sums, the others keep theirs */
 } ngd_fixup_info;
 int ngd_last_fixup(const ngd_engine *e, ngd_fixup_info *info);
 /* The accumulation phase of the last run that took the spilled-terms plan (EM path, bootstrap blocks too small for

@@ -56,7 +56,8 @@ class NgdSpillTiming(C.Structure):
 
 
 class NgdFixupInfo(C.Structure):
-    _fields_ = [("flagged", C.c_uint64), ("recomputed", C.c_uint64), ("skipped", C.c_uint64), ("ms", C.c_double)]
+    _fields_ = [("flagged", C.c_uint64), ("recomputed", C.c_uint64), ("skipped", C.c_uint64), ("ms", C.c_double),
+                ("by_pass", C.c_uint64)]
 
 
 # every symbol include/ngsdist_amd.h declares (tests/test_abi.py checks the header against this)

@@ -62,6 +62,8 @@ struct ngd_engine {
   ngd_fix_tile *d_fixtiles = nullptr;  // 16 x 16 tiles of pairs that hold several noted pairs (fixup_pass)
   double *d_fixtparts = nullptr;       // ... and their per-slice partial sums
   uint64_t cap_fixtiles = 0, cap_fixtparts = 0;
+  double *fix_p = nullptr, *fix_q = nullptr, *d_fixnew = nullptr;  // the fix-up pass as a whole two-operand pass (fixup_by_pass)
+  uint64_t cap_fix_p = 0, cap_fix_q = 0, cap_fixnew = 0;
   ngd_fixup_info fix_info{};
   std::vector<ngd_tile> h_tiles16;  // host copy of the owned 16 x 16 tiles that hold a pair (the fix-up pass's "every pair")
   uint32_t fix_cap = 0;  // pairs the reductions can note for the fix-up pass (ngd_internal.h NGD_FIX_LIST): the capacity of d_fixlist
@@ -409,7 +411,7 @@ void ngd_destroy(ngd_engine *e) {
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
                   e->cnt_boot, e->d_W, e->d_M, e->d_drawn, e->d_bsum, e->d_bcnt, e->d_wslice, e->d_emcnt, e->d_D, e->d_nanflag,
-                  e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr, e->d_fixtiles, e->d_fixtparts};
+                  e->d_rowpg, e->SM, e->d_fixlist, e->d_fixcount, e->d_fixseen, e->d_fixparts, e->d_fixthr, e->d_fixtiles, e->d_fixtparts, e->fix_p, e->fix_q, e->d_fixnew};
   for (void *p : ptrs)
     if (p && !in_pieces(e, p)) hipFree(p);
   for (auto &r : e->piece_ranges) release_pieces(*r);
@@ -1222,14 +1224,47 @@ static void read_timing(ngd_engine *e, uint64_t n_eff, uint32_t launches, bool a
 //    forms the replicates again.
 // The tolerance is unconditional: EVERY noted pair is recomputed, in launches of bounded size, however many there are
 // (round 6; rounds 4-5 gave up on all of them past a budget of ~0.33 s).  More noted pairs than the list holds (fix_cap):
-// which ones is then unknown, and every tile of the upper triangle is recomputed whole -- the whole matrix in gen_dist()'s
-// own arithmetic ([measured] 6-7e11 pair-sites/s: ~0.8 s at cfg 3's size, for a data set of clones).  Only a caller who
-// SETS a budget (NGD_OPT_FIXUP_WORK != 0) gets the old behaviour: noted work above it is left as the one-image pass
-// computed it and ngd_last_fixup() reports the pairs as skipped.
+// which ones is then unknown, and every pair of the engine is recomputed.  Where the tiles of a single matrix would cost
+// more than the whole matrix in the two-image arithmetic (a data set of clones) it is recomputed that way, in one more
+// pass (fixup_by_pass above: 86 ms at cfg 3's size where the tiles take ~0.8 s).  Only a caller who SETS a budget
+// (NGD_OPT_FIXUP_WORK != 0) gets the old behaviour: noted work above it is left as the one-image pass computed it and
+// ngd_last_fixup() reports the pairs as skipped.
 // A pair's slices depend on the number of sites alone (not on how many other pairs were noted), so its recomputed bits do
 // not depend on the rest of the data set.
+// The whole matrix once more in the two-image arithmetic -- P and Q = score . P formed a range of k-groups at a time from
+// the image and SM (layout.hip k_pq_range), K1m over the pair of scratch images range by range, every block adding to its
+// plane of the slab (the walk of the single_image = 1 engines, launch_accumulate()) -- then the noting rule once more:
+// exactly the pairs it picks take the new sums.  Costs a pass and a half (~70 ms at cfg 3's size) WHATEVER the data, where
+// tile by tile a data set of clones costs 0.8 s: fixup_pass() takes this way when its tiles would cost more.
+static int fixup_by_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, const unsigned long long *d_cnt, double thr) {
+  const ngd_geom &g = e->g;
+  const uint64_t kstride = (uint64_t)g.n_ig * 64;
+  const uint64_t kg_lim = std::min<uint64_t>(g.n_kg, (3 * s_hi + 3) / 4);
+  // ranges of about 1 GiB per scratch image (two of them), every slice a piece of every range
+  const uint64_t span = std::max<uint64_t>(256, ((uint64_t)1 << 30) / (kstride * 8));
+  uint64_t n_ranges = 0;
+  const uint64_t piece = qb_piece(kg_lim, e->n_ks, span, &n_ranges);
+  const uint64_t range_kg = std::min<uint64_t>(kg_lim, piece * e->n_ks);
+  const uint64_t need = (range_kg + NGD_KG_TAIL) * kstride;
+  int rc = ensure_cap(e, &e->fix_p, &e->cap_fix_p, need);
+  if (rc) return rc;
+  if ((rc = ensure_cap(e, &e->fix_q, &e->cap_fix_q, need))) return rc;
+  if ((rc = ensure_cap(e, &e->d_fixnew, &e->cap_fixnew, ngd_n_pairs(g.n_ind)))) return rc;
+  for (uint64_t r = 0; r < n_ranges; r++) {
+    const uint64_t lo = std::min<uint64_t>(r * piece * e->n_ks, kg_lim), hi = std::min<uint64_t>(lo + piece * e->n_ks, kg_lim);
+    if (hi <= lo) break;
+    ngd_launch_pq_range(e->st, g, e->sc, e->PA, e->SM, ws, lo, hi + NGD_KG_TAIL, e->fix_p, e->fix_q);
+    ngd_launch_accum_mfma(e->st, g, e->fix_p, e->fix_q, nullptr, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, e->n_ks,
+                          piece, hi - lo, 0, 0, e->slab, e->d_clk, 0, r > 0);
+  }
+  ngd_launch_reduce(e->st, g, e->slab, e->n_ks, 1, e->d_tiles, e->n_tiles, e->d_fixnew, nullptr, 0, nullptr, 0.0);
+  ngd_launch_fix_merge(e->st, g, e->d_fixnew, d_sum, d_cnt, thr, e->d_tiles, e->n_tiles);
+  HIPCHK(hipGetLastError());
+  return NGD_OK;
+}
+
 static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
-                      uint32_t n_slab_slices, bool *patched) {
+                      uint32_t n_slab_slices, bool *patched, const unsigned long long *d_cnt = nullptr, double thr = 0.0) {
   if (patched) *patched = false;
   const uint32_t n = *(volatile uint32_t *)e->h_fixcount;
   e->fix_info.flagged += n;
@@ -1287,6 +1322,27 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
   if (capped && (double)tiles.size() * tile_cost + (double)singles.size() * (double)s_hi > budget) {
     e->fix_info.skipped += n;
     return NGD_OK;
+  }
+  // A single matrix whose tiles would cost more than the whole matrix by the two-operand MFMA arithmetic takes that way
+  // ([measured] tiles: 6.5e11 pair-sites/s of 256 each; the pass: 6 flop per pair-site at ~55 TF with its ranges' overhead
+  // + 80 bytes per (individual, site) to form the scratch images at ~2.4 TB/s)
+  if (d_sum && e->kernel == NGD_KERNEL_MFMA && e->exact_shapes == 0 && e->slab) {
+    const double t_tiles = ((double)tiles.size() * 256.0 + (double)singles.size() * 60.0) * (double)s_hi / 6.5e11;
+    const double t_pass = 6.0 * (double)e->n_owned_pairs * (double)s_hi / 55e12 + 80.0 * (double)e->g.n_pad * (double)s_hi / 2.4e12 + 2e-3;
+    if (t_tiles > t_pass) {
+      int rc = fixup_by_pass(e, ws, s_hi, d_sum, d_cnt, thr);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(t1, e->st));
+      HIPCHK(hipStreamSynchronize(e->st));
+      if (int rf = mfma_fault(e)) return rf;
+      float ms = 0;
+      hipEventElapsedTime(&ms, t0, t1);
+      e->fix_info.ms += ms;
+      e->fix_info.recomputed += all ? e->n_owned_pairs : n;
+      e->fix_info.by_pass += 1;
+      if (patched) *patched = true;
+      return NGD_OK;
+    }
   }
   // launches of at most 2^22 workgroups (HIP bounds a launch's threads by 2^32); a pass over per-block partial results has
   // one workgroup per (tile or pair, slab slice)
@@ -1435,7 +1491,9 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   HIPCHK(hipStreamSynchronize(e->st));
   read_timing(e, n_eff, 1, add_timing);
   if (int rc = mfma_fault(e)) return rc;
-  if (fix) return fixup_pass(e, ws, n_eff, d_sum, 0, 0, nullptr);
+  if (fix)
+    return fixup_pass(e, ws, n_eff, d_sum, 0, 0, nullptr, e->cfg.pairwise_del ? d_cnt : nullptr,
+                      NGD_FIX_MEAN * (double)(mult ? n_drawn : n_eff));
   return NGD_OK;
 }
 

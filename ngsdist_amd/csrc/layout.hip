@@ -96,6 +96,43 @@ __global__ __launch_bounds__(256) void k_qb_range(ngd_geom g, ngd_score sc, cons
     }
 }
 
+// Both operand images of the two-image arithmetic for a RANGE of k-groups, out of a congruent one-image engine's image T and
+// its side array SM = min(p0, p2) (fixup.hip has the recovery: p1 = t2, delta = +-t1, the smaller of p0 / p2 beside the
+// larger): Ps = p, Qs = score . p with emit()'s arithmetic, per-site weight folded into p (a bootstrap multiplicity: a small
+// integer).  One thread per (site, padded individual) of the sites that reach into [kg_lo, kg_end); scratch entries of
+// padding individuals, of sites past the data set and of the tail groups are written as zeros.
+__global__ void k_pq_range(ngd_geom g, ngd_score sc, const double *__restrict__ T, const double *__restrict__ SM,
+                           const uint32_t *__restrict__ ws, uint64_t s_first, uint64_t n_s, uint64_t kg_lo, uint64_t kg_end,
+                           double *__restrict__ Ps, double *__restrict__ Qs) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_s * g.n_pad) return;
+  const uint64_t s = s_first + e / g.n_pad;
+  const uint32_t i = (uint32_t)(e % g.n_pad);
+  double p0 = 0, p1 = 0, p2 = 0;
+  if (s < g.n_sites && i < g.n_ind) {
+    const uint64_t k = 3 * s;
+    const double d = sc.fix_sign * T[ngd_frag_off(k + 1, i, g.n_ig)];  // p2 - p0
+    const double m = T[ngd_frag_off(k + 2, i, g.n_ig)];
+    const double sm = SM[s * g.n_ind + i];
+    p1 = m;
+    p0 = d >= 0 ? sm : sm - d;
+    p2 = d >= 0 ? sm + d : sm;
+  }
+  const double w = (ws && s < g.n_sites) ? (double)ws[s] : 1.0;  // (on ONE operand: the product carries it once)
+  const double p[3] = {p0 * w, p1 * w, p2 * w};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const uint64_t k = 3 * s + a, kg = k >> 2;
+    if (kg < kg_lo || kg >= kg_end) continue;
+    double q = sc.v[3 * a] * p0;
+    q = q + sc.v[3 * a + 1] * p1;
+    q = q + sc.v[3 * a + 2] * p2;
+    const uint64_t off = ((kg - kg_lo) * g.n_ig + (i >> 4)) * 64 + (k & 3) * 16 + (i & 15);
+    Ps[off] = p[a];
+    Qs[off] = q;
+  }
+}
+
 __global__ void k_layout(ngd_geom g, const double *__restrict__ raw, int raw_ind_major, uint64_t s0,
                          uint64_t n_chunk, ngd_score sc, int pairwise_del, double *PA, double *QB,
                          double *PI, unsigned long long *mask) {
@@ -365,6 +402,15 @@ void ngd_launch_qb_range(hipStream_t st, const ngd_geom &g, const ngd_score &sco
   const uint64_t u_lo = kg_lo / 3, u_hi = (kg_hi + 2) / 3;  // every period of three k-groups with one in the range
   const uint64_t n_blk = (u_hi - u_lo + QB_PER - 1) / QB_PER * (g.n_ig >> 2);
   hipLaunchKernelGGL(k_qb_range, dim3((unsigned)n_blk), dim3(256), 0, st, g, score, PA, u_lo, u_hi, kg_lo, kg_hi, QBs);
+}
+
+void ngd_launch_pq_range(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,
+                         const uint32_t *d_ws, uint64_t kg_lo, uint64_t kg_end, double *Ps, double *Qs) {
+  if (kg_end <= kg_lo) return;
+  const uint64_t s_first = 4 * kg_lo / 3, s_last = (4 * kg_end + 2) / 3;  // every site with an index in [4 kg_lo, 4 kg_end)
+  const uint64_t n = (s_last - s_first) * g.n_pad;
+  hipLaunchKernelGGL(k_pq_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, score, T, SM, d_ws, s_first,
+                     s_last - s_first, kg_lo, kg_end, Ps, Qs);
 }
 
 void ngd_launch_layout(hipStream_t st, const ngd_geom &g, const double *raw, int raw_ind_major,

@@ -243,6 +243,11 @@ void ngd_launch_reduce(hipStream_t st, const ngd_geom &g, const double *slab, ui
                        const ngd_fix_flags *fix = nullptr, double fix_thr = 0);
 // --pairwise_del: the pairs of d_sum / d_cnt ([n_rep][n_pairs]) that want the fix-up pass, decided with their valid-site
 // counts in hand (a pair with no valid site in a matrix is exactly 0 there and is not noted); fix.count zeroed by the caller
+// layout.hip / reduce.hip : the fix-up pass as ONE two-operand pass over scratch images formed a range of k-groups at a time
+void ngd_launch_pq_range(hipStream_t st, const ngd_geom &g, const ngd_score &score, const double *T, const double *SM,
+                         const uint32_t *d_ws, uint64_t kg_lo, uint64_t kg_end, double *Ps, double *Qs);
+void ngd_launch_fix_merge(hipStream_t st, const ngd_geom &g, const double *d_new, double *d_sum, const unsigned long long *d_cnt,
+                          double thr, const ngd_tile *d_tiles, uint32_t n_tiles);
 void ngd_launch_fix_flag(hipStream_t st, const ngd_geom &g, const double *d_sum, const unsigned long long *d_cnt,
                          uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, const ngd_fix_flags &fix);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it

@@ -154,6 +154,28 @@ __global__ __launch_bounds__(128) void k_fix_flag(const double *__restrict__ d_s
   }
 }
 
+// The fix-up pass by a whole two-operand pass (engine.hip fixup_by_pass): d_new holds every pair's sum in the two-image
+// arithmetic; it replaces the one-image sum of exactly the pairs the noting rule picks (sum below mean x the sites visited;
+// under --pairwise_del x the pair's own count, never a pair without a valid site) -- all others keep their bits.
+__global__ __launch_bounds__(128) void k_fix_merge(const double *__restrict__ d_new, double *__restrict__ d_sum,
+                                                    const unsigned long long *__restrict__ d_cnt, double thr, double mean,
+                                                    const ngd_tile *__restrict__ tiles, uint64_t n_ind) {
+  const uint32_t tile = blockIdx.x >> 7, row = blockIdx.x & 127;
+  const uint32_t i = tiles[tile].ti * NGD_TILE + row;
+  const uint32_t j = tiles[tile].tj * NGD_TILE + threadIdx.x;
+  if (!(i < j && j < n_ind)) return;
+  const uint64_t idx = ngd_pair_idx(n_ind, i, j);
+  const double old = d_sum[idx];
+  bool small;
+  if (d_cnt) {
+    const unsigned long long c = d_cnt[idx];
+    small = c != 0 && old < mean * (double)c;
+  } else {
+    small = old < thr;
+  }
+  if (small) d_sum[idx] = d_new[idx];
+}
+
 // The same for the valid-site counts of --pairwise_del: cnt[r][pair] = SUM_b M[b][r] * C[b][pair] with
 // C = per-block popcounts (k_count_blocks) and M the block multiplicities (uint32, block-major).
 template <int RB>
@@ -343,6 +365,13 @@ void ngd_launch_fix_flag(hipStream_t st, const ngd_geom &g, const double *d_sum,
   if (!n_tiles || !n_rep) return;
   hipLaunchKernelGGL(k_fix_flag, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, d_sum, d_cnt, n_rep, d_tiles, g.n_ind,
                      ngd_n_pairs(g.n_ind), NGD_FIX_MEAN, fix);
+}
+
+void ngd_launch_fix_merge(hipStream_t st, const ngd_geom &g, const double *d_new, double *d_sum, const unsigned long long *d_cnt,
+                          double thr, const ngd_tile *d_tiles, uint32_t n_tiles) {
+  if (!n_tiles) return;
+  hipLaunchKernelGGL(k_fix_merge, dim3(n_tiles * NGD_TILE), dim3(128), 0, st, d_new, d_sum, d_cnt, thr, NGD_FIX_MEAN, d_tiles,
+                     g.n_ind);
 }
 
 // replicates per pass over the partials; the weight arrays are padded to a multiple of it

@@ -124,7 +124,7 @@ def test_cfg3_single_image_engine(cfg3_mfma):
         e.synth_fill(3)
         assert e.device_bytes() < 36e9
         s, c = e.run()
-        assert e.fixup() == {"flagged": 0, "recomputed": 0, "skipped": 0, "ms": 0.0}
+        assert e.fixup() == {"flagged": 0, "recomputed": 0, "skipped": 0, "ms": 0.0, "by_pass": 0}
         assert np.array_equal(c, cnt) and rel(s, full) < 1e-12
         assert np.array_equal(e.run()[0], s)
         e.set_option("boot_partials", 2)
@@ -148,7 +148,8 @@ def test_one_image_engine_recomputes_a_large_data_set_of_clones_whatever_it_cost
     """1400 copies of one individual x 250 000 sites: 979 300 noted pairs in 3916 tiles = 4.2e9 pair-sites of recomputation --
     above the 4.1e9 at which the engines of rounds 4-5 gave up on ALL of them and returned the one-image sums (absolute
     error 4e-17 per site, i.e. 1e-3 relative on these sums of ~1e-8 per site).  The default engine now recomputes every one:
-    1e-9 relative against the two-image engine on every pair and against the oracle on the pairs of 12 individuals."""
+    1e-9 relative against the two-image engine on every pair and against the oracle on the pairs of 12 individuals -- by ONE
+    more pass in the two-image arithmetic over scratch images (engine.hip fixup_by_pass), since 3916 tiles cost more."""
     n_ind, n_sites, eps, chunk = 1400, 250_000, 1e-9, 25_000
     sub = np.array([0, 1, 15, 16, 17, 200, 640, 641, 900, 1398, 1399, 777])
     keep = []
@@ -166,6 +167,16 @@ def test_one_image_engine_recomputes_a_large_data_set_of_clones_whatever_it_cost
         s1, c1 = e1.commit().run()
         f = e1.fixup()
         s2, c2 = e2.commit().run()
+        # a weighted pass (one bootstrap replicate, the weights inside the accumulation) the same way
+        m = N().Taus(3).block_map(n_sites // 1000)
+        for e in (e1, e2):
+            e.set_option("boot_partials", 0)
+        w1, wc1 = e1.run(m, 1000)
+        fw = e1.fixup()
+        w2, wc2 = e2.run(m, 1000)
+    assert fw["by_pass"] == 1 and fw["skipped"] == 0 and np.array_equal(wc1, wc2) and rel(w1, w2) < RTOL
+    # (3916 tiles x 250 000 sites would take 0.4 s tile by tile: the whole matrix once more in the two-image arithmetic instead)
+    assert f["by_pass"] == 1 and f["ms"] < 150
     assert f["flagged"] == f["recomputed"] == N().n_pairs(n_ind) and f["skipped"] == 0
     assert np.array_equal(c1, c2) and rel(s1, s2) < RTOL
     so, co = O.all_pairs(np.concatenate(keep, axis=1), n_threads=16)

@@ -591,6 +591,42 @@ def clones(n_ind, n_sites, eps, seed=5, n_free=0, hom_only=False):
     return p
 
 
+@pytest.mark.parametrize("pairwise_del", [False, True])
+def test_congruent_single_image_fixup_by_one_more_pass(pairwise_del):
+    """So many nearly identical pairs that their tiles would cost more than the whole matrix in the two-image arithmetic (500
+    copies x 20 000 sites: 528 tiles): the fix-up goes ONE more pass instead -- P and Q = score . P formed a range of
+    k-groups at a time from the image and min(p0, p2) (layout.hip k_pq_range), K1m over the scratch images, the noting rule
+    applied once more (reduce.hip k_fix_merge: the noted pairs take the new sums, the others keep their bits).  A plain pass
+    and a weighted one (bootstrap multiplicities folded into ONE operand), with 30 ordinary individuals whose pairs must keep
+    the one-image bits, against the oracle."""
+    n_ind, n_sites, B = 500, 20_000, 16
+    p = clones(n_ind, n_sites, 1e-10, n_free=30)
+    if pairwise_del:
+        miss = np.random.default_rng(4).random((n_ind, n_sites)) < 0.05
+        p[miss] = 1.0 / 3
+    so, co = O.all_pairs(p, pairwise_del=pairwise_del, n_threads=16)
+    m = N().Taus(9).block_map(n_sites // B)
+    sb, cb = O.all_pairs(p, pairwise_del=pairwise_del, site_src=O.boot_site_src(m, B), n_threads=16)
+    with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, kernel="mfma") as e:
+        assert e.image_mode() == (2, True)
+        e.upload_ind_major(p).commit()
+        e.set_option("fixup_work", 1)  # a budget of one pair-site: the one-image sums as they are, for the bits of the others
+        s0, _ = e.run()
+        assert e.fixup()["skipped"] > 0
+        e.set_option("fixup_work", 0)
+        s, c = e.run()
+        f = e.fixup()
+        assert f["by_pass"] == 1 and f["skipped"] == 0 and f["recomputed"] == f["flagged"] >= 470 * 469 // 2
+        assert np.array_equal(c, co) and rel_err(s, so) < RTOL
+        free = np.array([N()._lib.load().ngd_pair_index(n_ind, i, j) for i in range(470, n_ind) for j in range(i + 1, n_ind)])
+        assert np.array_equal(s[free], s0[free])  # ordinary pairs: not noted, not touched
+        assert rel_err(s0, so) > RTOL  # (the test would prove nothing if the one-image sums were good enough)
+        e.set_option("boot_partials", 0)
+        s2, c2 = e.run(m, B)
+        assert e.fixup()["by_pass"] == 1
+        assert np.array_equal(c2, cb) and rel_err(s2, sb) < RTOL
+
+
 @pytest.mark.parametrize("pairwise_del,n_rep", [(False, 0), (True, 3)])
 def test_congruent_single_image_more_noted_pairs_than_the_list_holds(pairwise_del, n_rep):
     """More than 2^20 pairs noted at once (1500 copies of one individual: 1 124 250 pairs): the list of noted pairs
