@@ -305,10 +305,17 @@ static void piece_worker(ngd_engine *e) {
   e->piece_cv.notify_all();
 }
 
-static void piece_start(ngd_engine *e) {
-  if (e->piece_ranges.empty()) return;
+// (a reserved address range costs nothing: what the ranges will take is checked against the device's free memory HERE, so
+// that a data set that cannot fit is refused by ngd_create -- NGD_E_NOMEM -- and not by the first upload)
+static int piece_start(ngd_engine *e) {
+  if (e->piece_ranges.empty()) return NGD_OK;
+  size_t free_b = 0, total_b = 0, want = 0;
+  for (auto &q : e->piece_ranges) want += q->size;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b)
+    return fail(NGD_E_NOMEM, "ngd_create: the images and slabs of this data set exceed the device's free memory");
   e->piece_done = false;
   e->piece_thread = std::thread(piece_worker, e);
+  return NGD_OK;
 }
 
 // every piece of every range is there (or the worker has failed: its error)
@@ -843,7 +850,7 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     if (cfg->n_slices) ks = std::min<uint64_t>(cfg->n_slices, g.n_sites);  // never more slices than sites
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
-    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
+    TRY(dev_alloc_pieces(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, true));
     TRY(dev_alloc(e, &e->d_emcnt, 4, true));
     {
       // pair slots of the spilled-terms plan (em_spill_impl): a row of a tile takes one slot group per group of 16 columns
@@ -875,14 +882,14 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     if (cfg->n_slices) ks = std::min<uint64_t>(cfg->n_slices, g.n_sites);  // never more slices than sites
     e->n_ks = (uint32_t)ks;
     e->per_slice = (g.n_sites + ks - 1) / ks;
-    TRY(dev_alloc(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
+    TRY(dev_alloc_pieces(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
   }
   // upload staging: at most ~256 MiB of raw doubles
   e->staging_sites = std::max<uint64_t>(1, std::min<uint64_t>(g.n_sites, (256ull << 20) / (g.n_ind * 24)));
   TRY(dev_alloc(e, &e->staging, e->staging_sites * g.n_ind * 3, false));
 #undef TRY
   if (hipStreamSynchronize(e->st) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: sync failed"));
-  piece_start(e);  // the images' and slabs' memory arrives behind this call (dev_alloc_pieces)
+  if (int prc = piece_start(e)) return bail(prc);  // the images' and slabs' memory arrives behind this call (dev_alloc_pieces)
   *out = e;
   return NGD_OK;
 }

@@ -206,41 +206,78 @@ int64_t ngd_format_matrix(const double *dist, uint64_t n_ind, const char *const 
   unsigned nt = n_threads ? n_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (n_ind < 64) nt = 1;
   nt = (unsigned)std::min<uint64_t>(nt, n_ind);
-  std::vector<std::string> part(nt);
+  // shares of rows, finer than the threads (rows near the top hold more upper-triangle cells: dist is read row-wise there,
+  // column-wise below the diagonal); every share formats into a buffer of its own, sized by the longest a cell can be
+  const unsigned n_parts = nt == 1 ? 1 : (unsigned)std::min<uint64_t>(n_ind, 4ull * nt);
+  struct Part { std::vector<char> buf; size_t len = 0; };
+  std::vector<Part> part(n_parts);
+  std::vector<size_t> label_len(n_ind);
+  for (uint64_t i = 0; i < n_ind; i++) label_len[i] = strlen(labels[i]);
   auto rows = [&](unsigned t) {
-    const uint64_t lo = n_ind * t / nt, hi = n_ind * (t + 1) / nt;
-    std::string &s = part[t];
-    s.reserve((hi - lo) * (n_ind * 14 + 32));
-    char cell[416];
+    const uint64_t lo = n_ind * t / n_parts, hi = n_ind * (t + 1) / n_parts;
+    size_t need = 0;
+    for (uint64_t i = lo; i < hi; i++) need += label_len[i] + n_ind * 24 + 1;  // ("\t" + sign + 9 digits + "." + 10 = 22 at most below 2^29)
+    Part &P = part[t];
+    P.buf.resize(need + 512);
+    char *o = P.buf.data(), *lim = o + P.buf.size() - 450;  // (a cell snprintf may write -- 2^29 and above, 1e300 -- needs up to ~330)
     for (uint64_t i = lo; i < hi; i++) {
-      s += labels[i];
-      for (uint64_t j = 0; j < n_ind; j++) {
-        // dist_matrix is symmetric with a zero diagonal (gen_dist_slave :411, init_ptr :200)
-        const double d = i == j ? 0.0 : i < j ? dist[i * (2 * n_ind - i - 1) / 2 + (j - i - 1)]
-                                              : dist[j * (2 * n_ind - j - 1) / 2 + (i - j - 1)];
-        cell[0] = '\t';
-        char *end = fmt_fixed10(d, cell + 1);
-        s.append(cell, (size_t)(end - cell));
+      memcpy(o, labels[i], label_len[i]);
+      o += label_len[i];
+      // dist_matrix is symmetric with a zero diagonal (gen_dist_slave :411, init_ptr :200): cells (j, i), j < i, walk down
+      // a column of the upper triangle -- pair index j (2n - j - 1) / 2 + (i - j - 1), its step from j to j + 1 is n - j - 2
+      uint64_t k = i - 1;  // (j = 0)
+      for (uint64_t j = 0; j < i; j++) {
+        if (o > lim) {  // huge cells: grow (never for distances)
+          const size_t used = (size_t)(o - P.buf.data());
+          P.buf.resize(P.buf.size() * 2 + 1024);
+          o = P.buf.data() + used;
+          lim = P.buf.data() + P.buf.size() - 450;
+        }
+        *o++ = '\t';
+        o = fmt_fixed10(dist[k], o);
+        k += n_ind - j - 2;
       }
-      s += '\n';
+      if (o > lim) { const size_t used = (size_t)(o - P.buf.data()); P.buf.resize(P.buf.size() * 2 + 1024); o = P.buf.data() + used; lim = P.buf.data() + P.buf.size() - 450; }
+      *o++ = '\t';
+      o = fmt_fixed10(0.0, o);
+      const double *row = dist + i * (2 * n_ind - i - 1) / 2 - (i + 1);  // row[j] = cell (i, j), j > i
+      for (uint64_t j = i + 1; j < n_ind; j++) {
+        if (o > lim) {
+          const size_t used = (size_t)(o - P.buf.data());
+          P.buf.resize(P.buf.size() * 2 + 1024);
+          o = P.buf.data() + used;
+          lim = P.buf.data() + P.buf.size() - 450;
+        }
+        *o++ = '\t';
+        o = fmt_fixed10(row[j], o);
+      }
+      *o++ = '\n';
+    }
+    P.len = (size_t)(o - P.buf.data());
+  };
+  const bool own_threads = n_threads && n_threads > 16;  // more threads asked for than the pool holds: this call's own
+  auto run_parts = [&](const std::function<void(unsigned)> &fn) {
+    if (nt == 1) {
+      for (unsigned t = 0; t < n_parts; t++) fn(t);
+    } else if (own_threads) {
+      std::atomic<unsigned> next{0};
+      std::vector<std::thread> th;
+      for (unsigned w = 0; w < nt; w++)
+        th.emplace_back([&]() { for (unsigned t; (t = next.fetch_add(1)) < n_parts;) fn(t); });
+      for (auto &t : th) t.join();
+    } else {
+      host_pool().run(n_parts, fn);
     }
   };
-  if (nt == 1) rows(0);
-  else if (n_threads && n_threads > 16) {  // more threads asked for than the pool holds: this call's own
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back(rows, t);
-    for (auto &t : th) t.join();
-  } else {
-    host_pool().run(nt, rows);
-  }
+  run_parts(rows);
   char head[32];
   const int hn = snprintf(head, sizeof(head), "\n%lu\n", (unsigned long)n_ind);
   uint64_t total = (uint64_t)hn;
-  for (auto &s : part) total += s.size();
+  std::vector<uint64_t> at(n_parts);
+  for (unsigned t = 0; t < n_parts; t++) { at[t] = total; total += part[t].len; }
   if (out && cap >= total) {
     memcpy(out, head, (size_t)hn);
-    char *o = out + hn;
-    for (auto &s : part) { memcpy(o, s.data(), s.size()); o += s.size(); }
+    run_parts([&](unsigned t) { memcpy(out + at[t], part[t].buf.data(), part[t].len); });  // (13 MB for 1000 individuals: in parallel too)
   }
   return (int64_t)total;
 }
