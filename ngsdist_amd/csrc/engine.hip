@@ -224,7 +224,7 @@ static int dev_alloc_pieces(ngd_engine *e, T **p, uint64_t count, bool zero, ngd
                             uint64_t bytes_per_site = 0) {
   *p = nullptr;
   const uint64_t bytes = count * sizeof(T);
-  if (bytes < ((uint64_t)1 << 30)) return dev_alloc(e, p, count, zero);
+  if (bytes < ((uint64_t)512 << 20)) return dev_alloc(e, p, count, zero);
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
@@ -884,9 +884,9 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
     e->per_slice = (g.n_sites + ks - 1) / ks;
     TRY(dev_alloc_pieces(e, &e->slab, ks * (uint64_t)g.n_pad * g.n_pad, false));
   }
-  // upload staging: at most ~256 MiB of raw doubles
+  // upload staging (ngd_upload_sites / _ind_major): at most ~256 MiB of raw doubles, allocated by the first upload that
+  // needs it (a staged load -- ngd_stage_* -- never does)
   e->staging_sites = std::max<uint64_t>(1, std::min<uint64_t>(g.n_sites, (256ull << 20) / (g.n_ind * 24)));
-  TRY(dev_alloc(e, &e->staging, e->staging_sites * g.n_ind * 3, false));
 #undef TRY
   if (hipStreamSynchronize(e->st) != hipSuccess) return bail(fail(NGD_E_HIP, "ngd_create: sync failed"));
   if (int prc = piece_start(e)) return bail(prc);  // the images' and slabs' memory arrives behind this call (dev_alloc_pieces)
@@ -900,6 +900,8 @@ static int upload_common(ngd_engine *e, const double *p, int ind_major, uint64_t
   if (s0 + n > e->g.n_sites || s0 + n < s0) return fail(NGD_E_INVALID, "upload: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
   if (int rc = piece_join(e)) return rc;
+  if (!e->staging)
+    if (int rc = dev_alloc(e, &e->staging, e->staging_sites * e->g.n_ind * 3, false)) return rc;
   const uint64_t n_ind = e->g.n_ind;
   for (uint64_t done = 0; done < n;) {
     const uint64_t c = std::min(e->staging_sites, n - done);

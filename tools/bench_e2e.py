@@ -159,6 +159,8 @@ def main():
         walls, phases_all, last_err = [], [], ""
         for r in range(args.runs):
             time.sleep(args.gap)
+            if os.path.exists(out):  # (truncating the previous run's output -- 1.3 GB of text for the EM bootstrap job: 0.1 s
+                os.remove(out)       # in tmpfs -- is not this run's work)
             t0 = time.perf_counter()
             pr = subprocess.run(cmd, capture_output=True, text=True)
             walls.append(time.perf_counter() - t0)
