@@ -7,6 +7,7 @@ import gzip
 import hashlib
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -488,3 +489,17 @@ def test_bgzf_text_is_inflated_on_several_threads_and_prints_the_same_bytes(tmp_
     r = subprocess.run([BIN, "--geno", bz, "--n_threads", "4", "--n_ind", "24", "--n_sites", "9999", "--out", str(tmp_path / "x")],
                        capture_output=True)
     assert r.returncode != 0 and b"not at EOF" in r.stderr
+
+
+def test_end_to_end_bench_tool_checks_every_printed_cell(tmp_path):
+    """tools/bench_e2e.py on cfg 2 (200 x 1e5, a 0.48 GB file): the host runs from a generated file through the mapped-file
+    loader (ring of pinned buffers, device memory in pieces), reports its phases, and every printed cell agrees with an
+    engine filled on the device from the same seed."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_e2e.py"), "--workloads", "cfg2", "--runs", "2", "--gap", "0",
+                        "--no_roof", "--dir", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["valid"] is True and line["check"]["cells"] == 19900
+    ph = line["phases_s"]
+    assert ph["load"] > 0 and ph["total_since_main"] <= line["wall_s"] and "of_load_read" in ph
