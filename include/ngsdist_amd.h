@@ -305,6 +305,12 @@ int ngd_drop_caches(ngd_engine *e);
                                  /* 4e-17 per site instead of 1e-9 relative) and says so in ngd_last_fixup().skipped           */
 #define NGD_OPT_STAGE_PIECE_MIB 10 /* [32] ngd_stage_acquire: MiB of raw input per pinned buffer                        */
 #define NGD_OPT_STAGE_RING 11     /* [6] ... and how many of them (2 .. 8); both before the first ngd_stage_acquire    */
+#define NGD_OPT_EAGER_FULL 12     /* [0] 1: a staged load (ngd_stage_*) of sites in ascending order starts the plain         */
+                                 /* full-data pass beside itself: leading slices of the site axis are accumulated, on a       */
+                                 /* low-priority stream, as soon as all their sites are prepared; the first ngd_run() with    */
+                                 /* no block map launches only what is left.  Same bits as without it.  For a host whose     */
+                                 /* first call after ngd_commit IS that pass (no bootstrap): anything else drops the work.    */
+                                 /* MFMA kernel above 384 padded individuals and the table-driven EM kernel; else ignored.    */
 #define NGD_OPT_DEBUG_FORGE_JOB 100 /* tests only: the first block of the MFMA kernel's job list gets the shape rows | cols << 3 |  */
                                  /*     tri << 6 -- a shape the kernel's block form does not list must fail the run with      */
                                  /*     NGD_E_HIP (its sums poisoned with NaN), never return zeros                            */

@@ -755,6 +755,33 @@ void ngd_launch_accum_em_table(hipStream_t st, const ngd_geom &g, const double *
 #undef NGD_EMT
 }
 
+// Slices ks0 .. ks0 + n_sub - 1 of a plain (unweighted) pass on their own -- the sites of the others need not be resident yet
+// (engine.hip: the full-data pass started during a staged load).  lds_pad: bytes of dynamic LDS a workgroup asks for on top
+// of its tables: enough of it and a CU holds ONE workgroup instead of two, which leaves registers and wave slots for the
+// preparation kernels of the pieces that are still arriving.
+void ngd_launch_accum_em_table_slices(hipStream_t st, const ngd_geom &g, const double *PA, const ngd_score &score, int pairwise_del,
+                                      int shape, const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t ks0, uint32_t n_sub,
+                                      uint64_t sites_per_slice, double *slab, unsigned long long *d_counters, uint32_t lds_pad) {
+  if (!n_tiles64 || !n_sub) return;
+  const uint64_t s_lo = (uint64_t)ks0 * sites_per_slice, s_hi = std::min<uint64_t>(g.n_sites, s_lo + (uint64_t)n_sub * sites_per_slice);
+  double *out = slab + (uint64_t)ks0 * g.n_pad * g.n_pad;
+  const bool p = pairwise_del != 0;
+#define NGD_EMT_S(NW, CH, WPS, P, K)                                                                                       \
+  hipLaunchKernelGGL((k_accum_em_table<NW, CH, WPS, false, P, K, 1>), dim3(n_tiles64 * n_sub), dim3(NW * 64), lds_pad, st, PA, \
+                     nullptr, nullptr, score, d_tiles64, n_tiles64, g.n_ig, g.n_pad, g.n_ind, s_hi, sites_per_slice, out,    \
+                     d_counters, s_lo)
+#define NGD_EMT_SP(NW, CH, WPS, K) do { if (p) NGD_EMT_S(NW, CH, WPS, true, K); else NGD_EMT_S(NW, CH, WPS, false, K); } while (0)
+  switch (shape) {
+    default: NGD_EMT_SP(8, 16, 4, true); break;
+    case 1: NGD_EMT_SP(4, 16, 2, false); break;
+    case 2: NGD_EMT_SP(8, 12, 4, false); break;
+    case 3: NGD_EMT_SP(4, 12, 2, false); break;
+    case 4: NGD_EMT_SP(8, 16, 4, false); break;
+  }
+#undef NGD_EMT_SP
+#undef NGD_EMT_S
+}
+
 // rb (4 or 8) matrices in one pass of the packed form; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
 void ngd_launch_accum_em_table_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
                                      uint64_t n_sites_eff, const ngd_score &score, int pairwise_del,

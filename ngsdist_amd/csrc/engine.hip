@@ -135,6 +135,16 @@ struct ngd_engine {
   // their own (the copy engine never waits for a preparation kernel), K0 follows each on the engine's stream
   static constexpr int RING = 8;
   uint64_t opt_stage_piece_mib = 32, opt_stage_ring = 6;  // NGD_OPT_STAGE_PIECE_MIB, NGD_OPT_STAGE_RING
+  // NGD_OPT_EAGER_FULL: the plain full-data pass starts DURING a staged load -- whenever enough leading slices of the site
+  // axis have all their sites prepared, they are accumulated on a low-priority stream of their own beside the copies and
+  // preparation kernels of the pieces still arriving; the first ngd_run() then launches what is left and reduces
+  bool opt_eager = false;
+  hipStream_t st_eager = nullptr;
+  hipEvent_t ev_eager = nullptr;
+  uint64_t stage_prefix = 0;   // sites [0, stage_prefix) have been submitted, in order
+  bool stage_in_order = true;
+  uint32_t eager_slices = 0;   // slices [0, eager_slices) of the plain pass have been launched on st_eager
+  bool eager_valid = false;
   double *pin[RING] = {}, *draw[RING] = {};
   hipEvent_t pin_free[RING] = {};  // the copy out of pin[b] is done: the caller may fill it again
   hipEvent_t k0_done[RING] = {};   // K0 has read draw[b]: the next copy may overwrite it
@@ -430,6 +440,8 @@ void ngd_destroy(ngd_engine *e) {
   }
   for (int c = 0; c < 2; c++)
     if (e->st_copy[c]) hipStreamDestroy(e->st_copy[c]);
+  if (e->st_eager) { hipStreamSynchronize(e->st_eager); hipStreamDestroy(e->st_eager); }
+  if (e->ev_eager) hipEventDestroy(e->ev_eager);
   if (e->h_clk) hipHostFree(e->h_clk);
   if (e->h_fixcount) hipHostFree(e->h_fixcount);
   if (e->d_nan) hipFree(e->d_nan);
@@ -939,6 +951,81 @@ static void stage_reap(ngd_engine *e) {
   if (e->ring_reaper.joinable()) e->ring_reaper.join();
 }
 
+// ---- the full-data pass beside a staged load (NGD_OPT_EAGER_FULL) ----
+static bool eager_supported(const ngd_engine *e) {
+  if (e->kernel == NGD_KERNEL_EM_TABLE) return e->n_ks > 1;
+  return e->kernel == NGD_KERNEL_MFMA && e->exact_shapes == 0 && !e->single_image && e->n_ks >= 16;
+}
+
+// slices [ks0, ks0 + n) of the plain pass on `st` (results: their planes of e->slab, as a whole launch leaves them)
+static void launch_plain_slices(ngd_engine *e, hipStream_t st, uint32_t ks0, uint32_t n, bool beside_a_load) {
+  const ngd_geom &g = e->g;
+  if (e->kernel == NGD_KERNEL_EM_TABLE) {
+    // beside a load ONE workgroup per CU (12 KB more LDS than its tables need): the chip is not full of workgroups that
+    // last tens of milliseconds when the next piece's preparation kernel wants wave slots and registers
+    ngd_launch_accum_em_table_slices(st, g, e->PA, e->sc, e->cfg.pairwise_del, e->em_shape, e->d_tiles64, e->n_tiles64, ks0, n,
+                                     e->per_slice, e->slab, e->d_emcnt, beside_a_load ? 12u << 10 : 0u);
+  } else {
+    ngd_launch_accum_mfma(st, g, e->PA, e->congruent ? e->PA : e->QB, e->congruent ? e->d_wD : nullptr, nullptr, e->d_jobs, e->n_wg,
+                          e->exact_shapes, e->wg_waves, n, e->per_slice, g.n_kg, 0, 0, e->slab, e->d_clk, ks0);
+  }
+}
+
+// after the piece of sites [s0, s0 + n) has been submitted (its preparation kernel is on e->st, k0_done[b] recorded)
+static int eager_advance(ngd_engine *e, uint64_t s0, uint64_t n, int b) {
+  if (!e->opt_eager || !e->stage_in_order) return NGD_OK;
+  if (s0 != e->stage_prefix) { e->stage_in_order = false; return NGD_OK; }  // (out of order: what is launched stays valid)
+  e->stage_prefix = s0 + n;
+  const ngd_geom &g = e->g;
+  if (e->stage_prefix >= g.n_sites) return NGD_OK;  // the last piece: ngd_run() launches what is left
+  uint32_t done;
+  if (e->kernel == NGD_KERNEL_EM_TABLE) {
+    done = (uint32_t)std::min<uint64_t>(e->n_ks, e->stage_prefix / e->per_slice);
+  } else {
+    // a slice's k-groups + the NGD_KG_TAIL groups its operand pipeline runs ahead: index 4 kg + 3 belongs to site (4 kg + 3) / 3
+    const uint64_t kg_ready = 3 * e->stage_prefix / 4;  // k-groups whose every index is below 3 * prefix
+    const uint64_t full = kg_ready > NGD_KG_TAIL ? (kg_ready - NGD_KG_TAIL) / e->per_slice : 0;
+    done = (uint32_t)std::min<uint64_t>(e->n_ks, full) / 8 * 8;  // (launches of whole eights of slices: the XCD deal)
+  }
+  const uint32_t batch = e->kernel == NGD_KERNEL_EM_TABLE ? std::max(1u, e->n_ks / 32) : std::max(8u, e->n_ks / 8 / 8 * 8);
+  if (done < e->eager_slices + batch) return NGD_OK;
+  // ONE batch in flight at a time, and a bounded one: what is launched here runs beside the load at a reduced rate (the
+  // table-driven EM kernel with one workgroup per CU: 0.56 of its speed) and must not still be running long after it
+  // ([measured] every completed slice launched at once: cfg 4's matrix 4.0 s instead of 2.26)
+  if (e->eager_valid) {
+    const hipError_t q = hipEventQuery(e->ev_eager);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return NGD_OK; }
+    HIPCHK(q);
+  }
+  done = std::min(done, e->eager_slices + (e->kernel == NGD_KERNEL_EM_TABLE ? batch : 2 * batch));
+  {  // the slab's planes of these slices must be mapped (its memory arrives after the images': dev_alloc_pieces)
+    std::lock_guard<std::mutex> lk(e->piece_mu);
+    for (auto &q : e->piece_ranges)
+      if (q->va == (void *)e->slab && q->ready < std::min<size_t>(q->size, (size_t)done * g.n_pad * g.n_pad * 8)) return NGD_OK;  // (next piece)
+  }
+  if (!e->st_eager) {
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&e->st_eager, hipStreamNonBlocking, least));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_eager, hipEventDisableTiming));
+  }
+  HIPCHK(hipStreamWaitEvent(e->st_eager, e->k0_done[b], 0));  // this piece's preparation -- and every earlier one's -- is done
+  launch_plain_slices(e, e->st_eager, e->eager_slices, done - e->eager_slices, true);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_eager, e->st_eager));
+  e->eager_slices = done;
+  e->eager_valid = true;
+  return NGD_OK;
+}
+
+// anything but the plain pass is about to use the slab (or the engine is going away): what was started is waited for and dropped
+static int eager_discard(ngd_engine *e) {
+  if (e->eager_valid) HIPCHK(hipStreamSynchronize(e->st_eager));
+  e->eager_valid = false;
+  e->eager_slices = 0;
+  return NGD_OK;
+}
+
 static int stage_init(ngd_engine *e) {
   if (e->pin_sites) return NGD_OK;
   stage_reap(e);
@@ -1001,6 +1088,7 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
                          e->d_nan);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->k0_done[b], e->st));
+  if (int rc = eager_advance(e, s0, n, b)) return rc;
   e->pin_lent = -1;
   e->pin_cur = (b + 1) % e->ring_slots;
   return NGD_OK;
@@ -1468,7 +1556,13 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
   else if (list_pass)  // slices are equal shares of the list (whole multiples of 4 entries: the deepest operand ring)
     rc_acc = launch_accumulate(e, ws, e->d_kgl, n_eff, e->n_ks, (((uint64_t)n_list + e->n_ks - 1) / e->n_ks + 3) / 4 * 4,
                                n_list, e->slab);
-  else
+  else if (!mult && e->eager_valid && e->eager_slices) {
+    // the leading slices were accumulated beside the load (eager_advance): what is left, behind them
+    HIPCHK(hipStreamWaitEvent(e->st, e->ev_eager, 0));
+    if (e->eager_slices < e->n_ks) launch_plain_slices(e, e->st, e->eager_slices, e->n_ks - e->eager_slices, false);
+    e->eager_valid = false;
+    e->eager_slices = 0;
+  } else
     rc_acc = launch_accumulate(e, ws, nullptr, n_eff, e->n_ks, e->per_slice, g.n_kg, e->slab);
   if (rc_acc) return rc_acc;
   HIPCHK(hipGetLastError());
@@ -1942,6 +2036,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
   e->fix_info = ngd_fixup_info{};
   e->n_batch_valid = 0;  // (the matrices of an earlier batch are not this call's: set again by copy_out() on success)
   if (!n_rep) return pass_impl(e, nullptr, 0, 0, 0, 0, d_sum, d_cnt, false);
+  if (int rc = eager_discard(e)) return rc;  // (a job: its plans share passes between matrices; nothing of a plain pass is reused)
 
   if (!block_size || !n_blocks) return fail(NGD_E_INVALID, "ngd_run: empty bootstrap geometry");
   if (n_blocks > g.n_sites / block_size) return fail(NGD_E_INVALID, "ngd_run: n_blocks*block_size exceeds n_sites");
@@ -2195,6 +2290,10 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
       e->qb_chunk_kg = std::max<uint64_t>(1, (value ? value : 4ull << 30) / ((uint64_t)e->g.n_ig * 64 * 8));
       break;
     case NGD_OPT_FIXUP_WORK: e->opt_fix_work = value; break;
+    case NGD_OPT_EAGER_FULL:
+      if (e->pin_sites || e->committed) return fail(NGD_E_INVALID, "ngd_set_option: NGD_OPT_EAGER_FULL before the first ngd_stage_acquire");
+      e->opt_eager = value != 0 && eager_supported(e);  // (kernels without a slice-range launch: silently off)
+      break;
     case NGD_OPT_STAGE_PIECE_MIB:
     case NGD_OPT_STAGE_RING:
       if (e->pin_sites) return fail(NGD_E_INVALID, "ngd_set_option: the staging ring exists already (set before the first ngd_stage_acquire)");

@@ -183,6 +183,9 @@ void ngd_launch_spill_scatter(hipStream_t st, const double *D, uint32_t n_pg, co
                               const uint32_t *d_rowpg, uint64_t n_ind, uint32_t n_mat, double *d_sum);
 
 // rb (4, 8 or 16) replicates in one pass; d_Wb is [n_sites][rb] doubles, slab [n_ks][rb][n_pad][n_pad]
+void ngd_launch_accum_em_table_slices(hipStream_t st, const ngd_geom &g, const double *PA, const ngd_score &score, int pairwise_del,
+                                      int shape, const ngd_tile *d_tiles64, uint32_t n_tiles64, uint32_t ks0, uint32_t n_sub,
+                                      uint64_t sites_per_slice, double *slab, unsigned long long *d_counters, uint32_t lds_pad);
 void ngd_launch_accum_em_batch(hipStream_t st, const ngd_geom &g, const double *PA, const double *d_Wb, int rb,
                                uint64_t n_sites_eff, const ngd_score &score, int pairwise_del, int fast,
                                const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t n_ks,

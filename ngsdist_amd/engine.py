@@ -16,7 +16,7 @@ KERNELS = {"auto": 0, "stream": 1, "mfma": 2, "em_faithful": 3, "em_fast": 4, "e
 # NGD_OPT_* of include/ngsdist_amd.h
 OPTIONS = {"boot_partials": 1, "boot_max_bytes": 2, "boot_wg": 3, "boot_unaligned": 4, "em_batch": 5,
            "em_spill": 6, "em_spill_bytes": 7, "single_image_bytes": 8, "fixup_work": 9, "stage_piece_mib": 10,
-           "stage_ring": 11, "debug_forge_job": 100}
+           "stage_ring": 11, "eager_full": 12, "debug_forge_job": 100}
 
 # parse_args.cpp:25-27
 DEFAULT_SCORE = (0.0, 0.5, 1.0, 0.5, 0.0, 0.5, 1.0, 0.5, 0.0)

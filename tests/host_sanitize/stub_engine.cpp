@@ -80,6 +80,7 @@ int ngd_set_option(ngd_engine *e, int option, uint64_t value) {
   if (!e) return fail(NGD_E_INVALID, "stub: set_option");
   if (option == NGD_OPT_STAGE_PIECE_MIB) e->opt_piece_mib = value;
   else if (option == NGD_OPT_STAGE_RING) e->opt_ring = value;
+  else if (option == NGD_OPT_EAGER_FULL) (void)value;
   else return fail(NGD_E_INVALID, "stub: unknown option");
   return NGD_OK;
 }

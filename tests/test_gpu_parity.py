@@ -1146,3 +1146,40 @@ def test_random_shapes_flags_and_plans():
                                  n_sites=n_sites if m == 0 else n_eff, n_threads=4)
             assert np.array_equal(Cn[m], co), tag
             assert rel_err(S[m], so) < RTOL, tag
+
+
+@pytest.mark.parametrize("kernel,indep,n_ind,n_sites", [("mfma", True, 400, 120_000), ("mfma", True, 530, 60_000),
+                                                         ("em_table", False, 200, 40_000), ("em_table", False, 90, 30_000)])
+@pytest.mark.parametrize("pairwise_del", [False, True])
+def test_full_data_pass_started_beside_a_staged_load(kernel, indep, n_ind, n_sites, pairwise_del):
+    """NGD_OPT_EAGER_FULL: while the raw chunks of a staged load are still arriving (ngd_stage_acquire / submit: copies and
+    the preparation kernel K0 on their streams), the leading slices of the plain full-data pass are accumulated on a
+    low-priority stream of their own; the first run() launches only what is left.  Same BITS as the same engine without it
+    (a slice's plane of the slab is computed by the same code on the same data whenever it runs), the oracle's values, and a
+    second run() -- nothing eager left -- the same again; a bootstrap call first simply drops the eager work."""
+    raw = np.ascontiguousarray(O.synth_indmajor(77, n_ind, n_sites, miss_frac=0.05 if pairwise_del else 0.0).transpose(1, 0, 2))
+    p = np.ascontiguousarray(raw.transpose(1, 0, 2))
+    res = {}
+    for eager in (0, 1):
+        with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, indep_geno=indep, kernel=kernel) as e:
+            e.set_option("stage_piece_mib", 1)  # many pieces, so that slices complete while later ones are still in flight
+            e.set_option("eager_full", eager)
+            e.upload_raw_sites(raw, 0).commit()
+            s1, c1 = e.run()
+            s2, c2 = e.run()
+            m = N().Taus(3).block_map(n_sites // 50)
+            sb, cb = e.run(m, 50)
+            res[eager] = (s1, c1, sb, cb)
+            assert np.array_equal(s1, s2) and np.array_equal(c1, c2)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    so, co = O.all_pairs(p, pairwise_del=pairwise_del, indep_geno=indep, n_threads=16)
+    assert np.array_equal(res[1][1], co) and rel_err(res[1][0], so) < RTOL
+    with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, indep_geno=indep, kernel=kernel) as e:
+        e.set_option("stage_piece_mib", 1)
+        e.set_option("eager_full", 1)
+        e.upload_raw_sites(raw, 0).commit()
+        sb2, cb2 = e.run(m, 50)  # a replicate FIRST: the eager slices are dropped
+        assert np.array_equal(sb2, res[0][2]) and np.array_equal(cb2, res[0][3])
+        s3, c3 = e.run()
+        assert np.array_equal(s3, res[0][0])
