@@ -1004,6 +1004,9 @@ static int eager_advance(ngd_engine *e, uint64_t s0, uint64_t n, int b) {
       if (q->va == (void *)e->slab && q->ready < std::min<size_t>(q->size, (size_t)done * g.n_pad * g.n_pad * 8)) return NGD_OK;  // (next piece)
   }
   if (!e->st_eager) {
+    // (a stream confined to a part of the CUs -- hipExtStreamCreateWithCUMask, 7/8 or 3/4 of them -- lets the EM kernel keep
+    // two workgroups per CU there and does more beside the load, but the preparation kernels then wait for the few CUs
+    // left: [measured] cfg 4 end to end 2.78-2.83 and 2.89-2.92 s against 2.77-2.80 with the plain low-priority stream)
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPCHK(hipStreamCreateWithPriority(&e->st_eager, hipStreamNonBlocking, least));
