@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 5 /* 5: ngd_finish_stream, NGD_OPT_STAGE_PIECE_MIB / _STAGE_RING, NGD_OPT_FIXUP_WORK 0 = no budget (every noted pair is recomputed); 4: ngd_last_spill_timing, ngd_last_fixup, ngd_image_mode, ngd_config.single_image 0 = auto / 3 = two images; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
+#define NGD_ABI_VERSION 5 /* 5: ngd_finish_stream, ngd_fixup_info.by_pass, NGD_OPT_STAGE_PIECE_MIB / _STAGE_RING / _EAGER_FULL, NGD_OPT_FIXUP_WORK 0 = no budget (every noted pair is recomputed); 4: ngd_last_spill_timing, ngd_last_fixup, ngd_image_mode, ngd_config.single_image 0 = auto / 3 = two images; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
