@@ -30,7 +30,13 @@
 //    for, nearly identical individuals, are recomputed the two-operand way -- the engine's own choice above 384
 //    individuals; or both images always),
 //    --prep auto|host|device (where log/normalise/call/exp of a BINARY input run; auto =
-//    device, except host when genotypes are called so that calls are decided by glibc).
+//    device, except host when genotypes are called so that calls are decided by glibc),
+//    --eager 0|1|2 (1, the default: on the EM path without bootstrap the full-data pass starts beside the load,
+//    NGD_OPT_EAGER_FULL; 2: on the --indep_geno path too; 0: never), --stage piece_MiB,ring[,share_MiB[,drop]] (the load
+//    pipeline's geometry, for measurements: tools/r6_stage_sweep.sh);
+//  * a binary file is mapped and copied into the engine's ring of pinned buffers by --n_threads (4..16) threads, the
+//    copies to the device and the preparation kernel running behind; matrices are written by a thread of their own
+//    while the next one is formatted; --verbose 2 ends with a `> phases [s]:` line (where the run's wall time went).
 #include <fcntl.h>
 #include <getopt.h>
 #include <sys/mman.h>
