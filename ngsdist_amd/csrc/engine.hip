@@ -281,6 +281,11 @@ static void piece_worker(ngd_engine *e) {
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
+  // test hook (NGD_ENABLE_TEST_HOOKS=1): the NGD_TEST_FAIL_PIECE-th piece "runs out of memory" -- the path a real failure takes
+  long fail_at = -1, n_made = 0;
+  if (const char *hook = getenv("NGD_ENABLE_TEST_HOOKS"))
+    if (!strcmp(hook, "1"))
+      if (const char *k = getenv("NGD_TEST_FAIL_PIECE")) fail_at = atol(k);
   for (;;) {
     ngd_engine::PieceRange *r = nullptr;
     for (int whole = 0; whole < 2 && !r; whole++) {
@@ -294,6 +299,7 @@ static void piece_worker(ngd_engine *e) {
     if (!r) break;
     const size_t off = r->n_mapped * kPiece, len = std::min(kPiece, r->size - off);
     hipMemGenericAllocationHandle_t h;
+    if (fail_at >= 0 && n_made++ == fail_at) { hipStreamDestroy(sa); return give_up("hipMemCreate (test hook)", hipErrorOutOfMemory); }
     if ((err = hipMemCreate(&h, len, &prop, 0)) != hipSuccess) { hipStreamDestroy(sa); return give_up("hipMemCreate", err); }
     r->hs.push_back(h);
     if ((err = hipMemMap((char *)r->va + off, len, 0, h, 0)) != hipSuccess) { hipStreamDestroy(sa); return give_up("hipMemMap", err); }
@@ -349,7 +355,7 @@ static int piece_wait_sites(ngd_engine *e, uint64_t s_end) {
       continue;
     }
     e->piece_cv.wait(lk, [&] { return q->ready >= need || e->piece_done; });
-    if (e->piece_rc) return fail(e->piece_rc, e->piece_err.c_str());
+    if (q->ready < need && e->piece_rc) return fail(e->piece_rc, e->piece_err.c_str());  // (what IS mapped serves its sites)
   }
   return NGD_OK;
 }

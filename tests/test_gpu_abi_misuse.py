@@ -209,3 +209,71 @@ def test_a_block_shape_the_kernel_does_not_list_fails_the_run(form, shape, monke
         e.set_option("boot_partials", 2)
         with pytest.raises(N.NgdError):
             e.run(N.Taus(1).block_map(n_sites // 8), 8)
+
+
+def test_device_memory_that_runs_out_behind_ngd_create_is_reported_by_the_first_call_that_needs_it(monkeypatch):
+    """Images of a GiB and more are address ranges whose memory a thread of the engine maps 256 MiB at a time behind ngd_create
+    (engine.hip dev_alloc_pieces / piece_worker).  A piece that cannot be had -- forced here through the test hook
+    NGD_TEST_FAIL_PIECE -- is reported as NGD_E_NOMEM by the first call that needs the memory: the staged upload whose sites
+    reach the missing part (the pieces before it serve the sites before it), ngd_upload_*, ngd_commit, ngd_synth_fill; the
+    engine is destroyed cleanly and the device memory comes back."""
+    import ngsdist_amd as N
+    L = N._lib.load()
+
+    def free_now():
+        free0, tot0 = C.c_uint64(0), C.c_uint64(0)
+        assert L.ngd_device_memory(0, C.byref(free0), C.byref(tot0)) == 0
+        return free0.value
+
+    n_ind, n_sites = 600, 120_000  # one image + min(p0, p2): 640 x 120 000 x 24 = 1.8 GB -> 7 pieces, 0.6 GB -> hipMalloc
+    with N.Engine(n_ind, n_sites) as e:  # (warm-up: the runtime's own pools)
+        e.synth_fill(1).run()
+    base = free_now()
+    monkeypatch.setenv("NGD_ENABLE_TEST_HOOKS", "1")
+    monkeypatch.setenv("NGD_TEST_FAIL_PIECE", "3")
+    raw = np.ascontiguousarray(O.synth_indmajor(5, n_ind, 4000).transpose(1, 0, 2))
+    for how in ("stage", "upload", "synth", "commit"):
+        e = N.Engine(n_ind, n_sites)
+        assert e.image_mode() == (2, True)
+        with pytest.raises(N.NgdError) as ei:
+            if how == "stage":
+                e.upload_raw_sites(raw, 0)          # the first 4000 sites lie in the pieces that were mapped ...
+                e.upload_raw_sites(raw, 100_000)    # ... these do not
+            elif how == "upload":
+                e.upload_sites(raw, 0)
+            elif how == "synth":
+                e.synth_fill(3)
+            else:
+                e.commit()
+        assert ei.value.code == -4 and "piece by piece" in str(ei.value)  # NGD_E_NOMEM
+        e.close()
+    monkeypatch.delenv("NGD_TEST_FAIL_PIECE")
+    with N.Engine(n_ind, n_sites) as e:
+        s, c = e.synth_fill(1).run()
+        assert np.all(np.isfinite(s))
+    leaked = base - free_now()
+    assert leaked < (64 << 20), "device memory not returned: %d MiB" % (leaked >> 20)
+
+
+def test_eager_pass_with_pieces_uploaded_out_of_order_and_small_rings():
+    """NGD_OPT_EAGER_FULL only follows a load that arrives in site order; pieces out of order switch it off for the rest of the
+    load (what was launched stays valid).  NGD_OPT_STAGE_RING / _PIECE_MIB: the smallest ring, one-MiB pieces."""
+    import ngsdist_amd as N
+    n_ind, n_sites = 450, 50_000
+    p = O.synth_indmajor(9, n_ind, n_sites)
+    raw = np.ascontiguousarray(p.transpose(1, 0, 2))
+    so, co = O.all_pairs(p, n_threads=16)
+    half = n_sites // 2
+    for order in ((0, half), (half, 0)):
+        with N.Engine(n_ind, n_sites, kernel="mfma") as e:
+            e.set_option("stage_piece_mib", 1)
+            e.set_option("stage_ring", 2)
+            e.set_option("eager_full", 1)
+            with pytest.raises(N.NgdError):
+                e.set_option("stage_ring", 9)
+            for s0 in order:
+                e.upload_raw_sites(np.ascontiguousarray(raw[s0:s0 + half]), s0)
+            with pytest.raises(N.NgdError):
+                e.set_option("eager_full", 0)  # (the ring exists: too late)
+            s, c = e.commit().run()
+        assert np.array_equal(c, co) and np.max(np.abs(s - so) / np.abs(so)) < 1e-9
