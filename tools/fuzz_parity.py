@@ -120,7 +120,17 @@ for case in range(first, first + n_cases):
             e.set_option("em_spill", em_spill).set_option("em_spill_bytes", spill_bytes)
             if single:
                 e.set_option("single_image_bytes", single_bytes)
-            e.upload_ind_major(p).commit()
+            # (round 6, a generator of its own) a quarter of the one-engine cases arrive as RAW chunks through the staged
+            # upload -- a ring of 2..8 pinned buffers of 1 MiB, K0 on the device, device memory of the images in pieces --
+            # with the full-data pass started beside the load where the kernel takes slice ranges (NGD_OPT_EAGER_FULL)
+            rng_r6 = np.random.default_rng(11_000_000 + case)
+            if rng_r6.integers(0, 4) == 0:
+                e.set_option("stage_piece_mib", 1).set_option("stage_ring", int(rng_r6.integers(2, 9)))
+                e.set_option("eager_full", int(rng_r6.integers(0, 2)))
+                e.upload_raw_sites(np.ascontiguousarray(p.transpose(1, 0, 2)), 0).commit()
+                tag = tag + ("staged",)
+            else:
+                e.upload_ind_major(p).commit()
             S, Cn = e.run_job(maps, B)
         for m in sorted({0, n_rep // 2, n_rep}):
             src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
