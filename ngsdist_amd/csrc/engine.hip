@@ -430,6 +430,7 @@ void ngd_destroy(ngd_engine *e) {
   hipSetDevice(e->device);
   if (e->piece_thread.joinable()) e->piece_thread.join();
   if (e->st) hipStreamSynchronize(e->st);
+  if (e->st_eager) hipStreamSynchronize(e->st_eager);  // (slices started beside a load and never asked for)
   stage_reap(e);
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
@@ -446,7 +447,7 @@ void ngd_destroy(ngd_engine *e) {
   }
   for (int c = 0; c < 2; c++)
     if (e->st_copy[c]) hipStreamDestroy(e->st_copy[c]);
-  if (e->st_eager) { hipStreamSynchronize(e->st_eager); hipStreamDestroy(e->st_eager); }
+  if (e->st_eager) hipStreamDestroy(e->st_eager);
   if (e->ev_eager) hipEventDestroy(e->ev_eager);
   if (e->h_clk) hipHostFree(e->h_clk);
   if (e->h_fixcount) hipHostFree(e->h_fixcount);
@@ -912,12 +913,16 @@ int ngd_create(const ngd_config *cfg, ngd_engine **out) {
   return NGD_OK;
 }
 
+static int eager_discard(ngd_engine *e);
+
 static int upload_common(ngd_engine *e, const double *p, int ind_major, uint64_t s0, uint64_t n) {
   if (!e || !p) return fail(NGD_E_INVALID, "upload: null argument");
   if (e->committed) return fail(NGD_E_INVALID, "upload: data set already committed");
   if (s0 + n > e->g.n_sites || s0 + n < s0) return fail(NGD_E_INVALID, "upload: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
   if (int rc = piece_join(e)) return rc;
+  if (int rc = eager_discard(e)) return rc;  // (sites may be uploaded again: nothing accumulated beside a staged load is kept)
+  e->stage_in_order = false;
   if (!e->staging)
     if (int rc = dev_alloc(e, &e->staging, e->staging_sites * e->g.n_ind * 3, false)) return rc;
   const uint64_t n_ind = e->g.n_ind;
