@@ -1092,7 +1092,7 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
     return fail(NGD_E_INVALID, "ngd_stage_submit: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
   const int b = e->pin_lent;
-  hipStream_t cs = e->st_copy[e->n_staged++ & 1];
+  hipStream_t cs = e->st_copy[e->n_staged++ & 1];  // ([measured] all copies on ONE stream: the same 0.53 s at cfg 3)
   HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, cs));
   HIPCHK(hipEventRecord(e->pin_free[b], cs));
   HIPCHK(hipStreamWaitEvent(e->st, e->pin_free[b], 0));
