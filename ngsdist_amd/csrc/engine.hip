@@ -3,6 +3,8 @@
 // the reference's `for i1<i2: threadpool_add(gen_dist_slave)` block
 // (ngsDist.cpp:244-269).  There is no CPU fallback anywhere in this file: if
 // HIP is unusable every entry point fails with an error code.
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -146,6 +148,7 @@ struct ngd_engine {
   uint32_t eager_slices = 0;   // slices [0, eager_slices) of the plain pass have been launched on st_eager
   bool eager_valid = false;
   double *pin[RING] = {}, *draw[RING] = {};
+  bool pin_reg[RING] = {};  // pin[b] is registered host memory (pin_alloc), not hipHostMalloc's
   hipEvent_t pin_free[RING] = {};  // the copy out of pin[b] is done: the caller may fill it again
   hipEvent_t k0_done[RING] = {};   // K0 has read draw[b]: the next copy may overwrite it
   hipStream_t st_copy[2] = {nullptr, nullptr};
@@ -424,6 +427,7 @@ uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2) { return ngd_p
 uint64_t ngd_device_bytes(const ngd_engine *e) { return e ? e->dev_bytes : 0; }
 
 static void stage_reap(ngd_engine *e);
+static void pin_release(double *p, bool registered);
 
 void ngd_destroy(ngd_engine *e) {
   if (!e) return;
@@ -440,7 +444,7 @@ void ngd_destroy(ngd_engine *e) {
     if (p && !in_pieces(e, p)) hipFree(p);
   for (auto &r : e->piece_ranges) release_pieces(*r);
   for (int b = 0; b < ngd_engine::RING; b++) {
-    if (e->pin[b]) hipHostFree(e->pin[b]);
+    pin_release(e->pin[b], e->pin_reg[b]);
     if (e->draw[b]) hipFree(e->draw[b]);
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
     if (e->k0_done[b]) hipEventDestroy(e->k0_done[b]);
@@ -1046,17 +1050,45 @@ static int stage_init(ngd_engine *e) {
   e->pin_sites = std::max<uint64_t>(1, std::min<uint64_t>(e->g.n_sites, (e->opt_stage_piece_mib << 20) / (e->g.n_ind * 24)));
   // (a data set of fewer pieces than the ring has slots takes only that many)
   e->ring_slots = (int)std::min<uint64_t>(e->opt_stage_ring, (e->g.n_sites + e->pin_sites - 1) / e->pin_sites);
-  for (int c = 0; c < 2; c++)
-    if (!e->st_copy[c]) HIPCHK(hipStreamCreateWithFlags(&e->st_copy[c], hipStreamNonBlocking));
+  // ONE copy stream ([measured] copies alternating two streams load cfg 3 in the same 0.53 s, and a stream costs 7 ms to create)
+  if (!e->st_copy[0]) HIPCHK(hipStreamCreateWithFlags(&e->st_copy[0], hipStreamNonBlocking));
   e->n_staged = 0;
   e->pin_cur = 0;
   return e->d_nan ? NGD_OK : dev_alloc(e, &e->d_nan, 1, true);
 }
 
+// A pinned buffer of the ring: huge-page-backed host memory registered with the runtime where that works (hipHostMalloc
+// allocates, zeroes and pins 4-KB pages at ~6.5 GiB/s: 5 ms per 32-MiB slot, six of them before the ring turns once -- the
+// copy engine idles ~25 ms at the start of every load; [measured] see stage_slot's note in DESIGN.md section 3 K0), else
+// hipHostMalloc.  pin_reg[b] says which, for the release.
+static int pin_alloc(ngd_engine *e, int b, uint64_t bytes) {
+  e->pin_reg[b] = false;
+  void *m = nullptr;
+  const size_t huge = (size_t)2 << 20, len = (bytes + huge - 1) / huge * huge;
+  if (posix_memalign(&m, huge, len) == 0) {
+    (void)madvise(m, len, MADV_HUGEPAGE);
+    if (hipHostRegister(m, len, hipHostRegisterDefault) == hipSuccess) {
+      e->pin[b] = (double *)m;
+      e->pin_reg[b] = true;
+      return NGD_OK;
+    }
+    (void)hipGetLastError();
+    free(m);
+  }
+  HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
+  return NGD_OK;
+}
+
+static void pin_release(double *p, bool registered) {
+  if (!p) return;
+  if (registered) { (void)hipHostUnregister(p); free(p); }
+  else (void)hipHostFree(p);
+}
+
 static int stage_slot(ngd_engine *e, int b) {
   if (e->pin[b]) return NGD_OK;
   const uint64_t bytes = e->pin_sites * e->g.n_ind * 24;
-  HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
+  if (int rc = pin_alloc(e, b, bytes)) return rc;
   int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
   if (rc) return rc;
   HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
@@ -1092,7 +1124,8 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
     return fail(NGD_E_INVALID, "ngd_stage_submit: site range out of bounds");
   HIPCHK(hipSetDevice(e->device));
   const int b = e->pin_lent;
-  hipStream_t cs = e->st_copy[e->n_staged++ & 1];  // ([measured] all copies on ONE stream: the same 0.53 s at cfg 3)
+  hipStream_t cs = e->st_copy[0];
+  e->n_staged++;
   HIPCHK(hipMemcpyAsync(e->draw[b], e->pin[b], n * e->g.n_ind * 24, hipMemcpyHostToDevice, cs));
   HIPCHK(hipEventRecord(e->pin_free[b], cs));
   HIPCHK(hipStreamWaitEvent(e->st, e->pin_free[b], 0));
@@ -1133,10 +1166,10 @@ int ngd_commit(ngd_engine *e) {
     int flag = 0;
     HIPCHK(hipMemcpy(&flag, e->d_nan, sizeof(int), hipMemcpyDeviceToHost));
     {  // the pipeline is over: its buffers go back on a thread of their own (6 x hipHostFree + hipFree are ~30 ms)
-      struct Slot { double *pin, *draw; hipEvent_t a, b; };
+      struct Slot { double *pin, *draw; hipEvent_t a, b; bool reg; };
       std::vector<Slot> slots;
       for (int b = 0; b < ngd_engine::RING; b++) {
-        if (e->pin[b] || e->draw[b]) slots.push_back({e->pin[b], e->draw[b], e->pin_free[b], e->k0_done[b]});
+        if (e->pin[b] || e->draw[b]) slots.push_back({e->pin[b], e->draw[b], e->pin_free[b], e->k0_done[b], e->pin_reg[b]});
         if (e->draw[b]) e->dev_bytes -= e->pin_sites * e->g.n_ind * 24;
         e->pin[b] = nullptr; e->draw[b] = nullptr; e->pin_free[b] = nullptr; e->k0_done[b] = nullptr;
       }
@@ -1148,7 +1181,7 @@ int ngd_commit(ngd_engine *e) {
         e->ring_reaper = std::thread([slots, dev]() {
           (void)hipSetDevice(dev);
           for (const Slot &s : slots) {
-            if (s.pin) (void)hipHostFree(s.pin);
+            pin_release(s.pin, s.reg);
             if (s.draw) (void)hipFree(s.draw);
             if (s.a) (void)hipEventDestroy(s.a);
             if (s.b) (void)hipEventDestroy(s.b);

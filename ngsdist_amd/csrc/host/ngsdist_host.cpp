@@ -721,7 +721,10 @@ void Loader::load(Engine &eng, uint64_t n_part, bool last_part) {
   bool in_logscale = p.in_logscale;
   const bool device_prep = p.in_bin && (p.prep == 2 || (p.prep == 0 && !p.call_geno));
   std::vector<double> buf(device_prep ? 0 : chunk * n_ind * 3);
-  const unsigned n_io = std::min(16u, std::max(4u, p.n_threads));
+  // (12, not 16: with the engine's own threads 16 copying threads overrun a CPU quota of 16 and the whole process is
+  // throttled for a few ms every 100 ms -- [measured] gaps of 2-7 ms between copies at 100-ms intervals; 8-20 threads load
+  // cfg 3 in the same 0.51-0.53 s, the copy engine being the pace)
+  const unsigned n_io = std::min(12u, std::max(4u, p.n_threads));
   auto read_exact = [&](double *dst, uint64_t bytes) {
     if (raw_fd >= 0) {
       if (raw_off + bytes > raw_size) die("read_geno", "GENO file at premature EOF. Check GENO file and number of sites!");
