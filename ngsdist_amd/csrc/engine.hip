@@ -133,7 +133,7 @@ struct ngd_engine {
   uint32_t n_batch_valid = 0;  // matrices of the last batch / job call, still in d_bsum / d_bcnt (ngd_fetch_matrix)
   double *staging = nullptr;
   uint64_t staging_sites = 0;
-  // raw-input pipeline: a ring of pinned host buffers, each with its device buffer; the copies run on two streams of
+  // raw-input pipeline: a ring of pinned host buffers, each with its device buffer; the copies run on a stream of
   // their own (the copy engine never waits for a preparation kernel), K0 follows each on the engine's stream
   static constexpr int RING = 8;
   uint64_t opt_stage_piece_mib = 32, opt_stage_ring = 6;  // NGD_OPT_STAGE_PIECE_MIB, NGD_OPT_STAGE_RING
@@ -1106,8 +1106,8 @@ int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites
   rc = stage_slot(e, b);
   if (rc) return rc;
   // the copy out of this buffer, a turn of the ring ago, is done -- and so is the preparation kernel that read its device
-  // twin (it follows the copy on the engine's stream, ~30 us): waited for HERE, on the host, so that the copy streams carry
-  // no wait of their own ([measured] a stream-side wait on an event costs the copy engine ~50 us of idling per copy)
+  // twin (it follows the copy on the engine's stream, ~30 us): waited for HERE, on the host, so that the copy stream carries
+  // no wait of its own ([measured] a stream-side wait on an event costs the copy engine ~50 us of idling per copy)
   HIPCHK(hipEventSynchronize(e->k0_done[b]));
   e->pin_lent = b;
   *host_buf = e->pin[b];
