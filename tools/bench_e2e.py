@@ -30,12 +30,12 @@ from bench import WORKLOADS  # noqa: E402  (shapes, seeds, flags: one definition
 EXE = os.path.join(ROOT, "ngsdist_amd", "bin", "ngsDist")
 
 
-def build_tools():
+def build_tools(need_peak=True):
     gen = os.path.join(ROOT, "tools", "gen_gl_file")
-    if not os.path.exists(gen):
+    if not os.path.exists(gen) or os.path.getmtime(gen) < os.path.getmtime(gen + ".cpp"):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-pthread", "-o", gen, gen + ".cpp"])
     peak = os.path.join(ROOT, "tools", "pcie_peak")
-    if not os.path.exists(peak):
+    if need_peak and (not os.path.exists(peak) or os.path.getmtime(peak) < os.path.getmtime(peak + ".hip")):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-o", peak, peak + ".hip"])
     return gen, peak
 
@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--keep", action="store_true", help="leave the generated files in --dir")
     ap.add_argument("--host_args", default="", help="extra arguments for the host, e.g. '--two_images'")
     args = ap.parse_args()
-    gen, peak = build_tools()
+    gen, peak = build_tools(need_peak=not args.no_roof)
     roof = {} if args.no_roof else link_roof(peak)
     pinned = max([v for k, v in roof.items() if k.startswith("h2d_") and "stream" in k] or [0.0])
     if roof:
