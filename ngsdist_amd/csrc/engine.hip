@@ -148,7 +148,6 @@ struct ngd_engine {
   uint32_t eager_slices = 0;   // slices [0, eager_slices) of the plain pass have been launched on st_eager
   bool eager_valid = false;
   double *pin[RING] = {}, *draw[RING] = {};
-  bool pin_reg[RING] = {};  // pin[b] is registered host memory (pin_alloc), not hipHostMalloc's
   hipEvent_t pin_free[RING] = {};  // the copy out of pin[b] is done: the caller may fill it again
   hipEvent_t k0_done[RING] = {};   // K0 has read draw[b]: the next copy may overwrite it
   hipStream_t st_copy[2] = {nullptr, nullptr};
@@ -427,7 +426,7 @@ uint64_t ngd_pair_index(uint64_t n_ind, uint64_t i1, uint64_t i2) { return ngd_p
 uint64_t ngd_device_bytes(const ngd_engine *e) { return e ? e->dev_bytes : 0; }
 
 static void stage_reap(ngd_engine *e);
-static void pin_release(double *p, bool registered);
+static void pin_release(double *p);
 
 void ngd_destroy(ngd_engine *e) {
   if (!e) return;
@@ -444,7 +443,7 @@ void ngd_destroy(ngd_engine *e) {
     if (p && !in_pieces(e, p)) hipFree(p);
   for (auto &r : e->piece_ranges) release_pieces(*r);
   for (int b = 0; b < ngd_engine::RING; b++) {
-    pin_release(e->pin[b], e->pin_reg[b]);
+    pin_release(e->pin[b]);
     if (e->draw[b]) hipFree(e->draw[b]);
     if (e->pin_free[b]) hipEventDestroy(e->pin_free[b]);
     if (e->k0_done[b]) hipEventDestroy(e->k0_done[b]);
@@ -1057,32 +1056,19 @@ static int stage_init(ngd_engine *e) {
   return e->d_nan ? NGD_OK : dev_alloc(e, &e->d_nan, 1, true);
 }
 
-// A pinned buffer of the ring: huge-page-backed host memory registered with the runtime where that works (hipHostMalloc
-// allocates, zeroes and pins 4-KB pages at ~6.5 GiB/s: 5 ms per 32-MiB slot, six of them before the ring turns once -- the
-// copy engine idles ~25 ms at the start of every load; [measured] see stage_slot's note in DESIGN.md section 3 K0), else
-// hipHostMalloc.  pin_reg[b] says which, for the release.
+// A pinned buffer of the ring comes from hipHostMalloc (which allocates, zeroes and pins 4-KB pages at ~6.5 GiB/s: 5 ms per
+// 32-MiB slot, ~25 ms before the ring has turned once).  Round 6 tried huge-page host memory registered with the runtime
+// (posix_memalign + MADV_HUGEPAGE + hipHostRegister: the copies first to last byte 0.468 -> 0.440 s) and took it out again:
+// in a process that created and destroyed engine after engine (tools/fuzz_large.py, case ~55 of 80) the GPU faulted on a HOST
+// heap address -- registered ranges are handed back to malloc and come round again at the same addresses, and a
+// registration that is released late takes the next one's mapping with it.  hipHostMalloc's buffers never share addresses.
 static int pin_alloc(ngd_engine *e, int b, uint64_t bytes) {
-  e->pin_reg[b] = false;
-  void *m = nullptr;
-  const size_t huge = (size_t)2 << 20, len = (bytes + huge - 1) / huge * huge;
-  if (posix_memalign(&m, huge, len) == 0) {
-    (void)madvise(m, len, MADV_HUGEPAGE);
-    if (hipHostRegister(m, len, hipHostRegisterDefault) == hipSuccess) {
-      e->pin[b] = (double *)m;
-      e->pin_reg[b] = true;
-      return NGD_OK;
-    }
-    (void)hipGetLastError();
-    free(m);
-  }
   HIPCHK(hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault));
   return NGD_OK;
 }
 
-static void pin_release(double *p, bool registered) {
-  if (!p) return;
-  if (registered) { (void)hipHostUnregister(p); free(p); }
-  else (void)hipHostFree(p);
+static void pin_release(double *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 static int stage_slot(ngd_engine *e, int b) {
@@ -1166,10 +1152,10 @@ int ngd_commit(ngd_engine *e) {
     int flag = 0;
     HIPCHK(hipMemcpy(&flag, e->d_nan, sizeof(int), hipMemcpyDeviceToHost));
     {  // the pipeline is over: its buffers go back on a thread of their own (6 x hipHostFree + hipFree are ~30 ms)
-      struct Slot { double *pin, *draw; hipEvent_t a, b; bool reg; };
+      struct Slot { double *pin, *draw; hipEvent_t a, b; };
       std::vector<Slot> slots;
       for (int b = 0; b < ngd_engine::RING; b++) {
-        if (e->pin[b] || e->draw[b]) slots.push_back({e->pin[b], e->draw[b], e->pin_free[b], e->k0_done[b], e->pin_reg[b]});
+        if (e->pin[b] || e->draw[b]) slots.push_back({e->pin[b], e->draw[b], e->pin_free[b], e->k0_done[b]});
         if (e->draw[b]) e->dev_bytes -= e->pin_sites * e->g.n_ind * 24;
         e->pin[b] = nullptr; e->draw[b] = nullptr; e->pin_free[b] = nullptr; e->k0_done[b] = nullptr;
       }
@@ -1181,7 +1167,7 @@ int ngd_commit(ngd_engine *e) {
         e->ring_reaper = std::thread([slots, dev]() {
           (void)hipSetDevice(dev);
           for (const Slot &s : slots) {
-            pin_release(s.pin, s.reg);
+            pin_release(s.pin);
             if (s.draw) (void)hipFree(s.draw);
             if (s.a) (void)hipEventDestroy(s.a);
             if (s.b) (void)hipEventDestroy(s.b);
