@@ -379,3 +379,16 @@ def test_tens_of_thousands_of_individuals(kernel, indep):
             assert c[g] == co[k]
             assert abs(s[g] - so[k]) <= 1e-9 * abs(so[k])
             k += 1
+
+
+def test_random_large_shapes_against_a_two_image_engine():
+    """tools/fuzz_large.py, a dozen cases: the sizes where the one-image engine, its fix-up pass, device memory in pieces, staged
+    raw uploads and the eager pass are live, each against a two-image engine fed the plain way and the oracle on a few pairs
+    (the sweep that found the ring-buffer fault of round 6: profiles/r06_fuzz.txt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_large.py"), "20001", "12"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "12 cases from seed 20001, 0 bad" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

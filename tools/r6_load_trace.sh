@@ -7,6 +7,7 @@ TAG=${1:-0}
 F=/dev/shm/ngd_e2e_cfg3_1000x1000000_seed3.bin
 [ -f $F ] || $ROOT/tools/gen_gl_file $F 1000 1000000 3 16
 OUT=$ROOT/gpurun_out/r6/load_trace_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--geno $F --probs --n_ind 1000 --n_sites 1000000 --evol_model 1 --indep_geno --out /tmp/x.dist --verbose 2 --n_threads 16 $HOST_ARGS"
