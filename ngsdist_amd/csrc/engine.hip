@@ -6,6 +6,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -154,6 +155,12 @@ struct ngd_engine {
   uint64_t n_staged = 0;
   int ring_slots = 0;
   std::thread ring_reaper;  // gives the ring back after ngd_commit, beside whatever the caller does next
+  // The ring GROWS: its first buffer is made by the first ngd_stage_acquire, the others by a thread beside the load
+  // (hipHostMalloc: 5 ms per 32-MiB buffer); the load turns through the buffers that exist (ring_ready of them)
+  std::thread ring_maker;
+  std::atomic<int> ring_ready{0};
+  std::atomic<bool> ring_stop{false};  // the load is over: no more buffers are needed
+  int ring_maker_rc = 0;
   int pin_cur = 0, pin_lent = -1;
   uint64_t pin_sites = 0;
   int *d_nan = nullptr;
@@ -434,6 +441,8 @@ void ngd_destroy(ngd_engine *e) {
   if (e->piece_thread.joinable()) e->piece_thread.join();
   if (e->st) hipStreamSynchronize(e->st);
   if (e->st_eager) hipStreamSynchronize(e->st_eager);  // (slices started beside a load and never asked for)
+  e->ring_stop = true;
+  if (e->ring_maker.joinable()) e->ring_maker.join();
   stage_reap(e);
   void *ptrs[] = {e->PA, e->QB, e->QB_res, e->qb_chunk, e->PI, e->mask, e->planes, e->d_mult, e->d_ws, e->d_wk, e->d_wD, e->d_kgl, e->d_kgcnt,
                   e->d_tiles, e->d_tiles16, e->d_tiles64, e->d_pairs, e->d_jobs, e->slab, e->d_sum, e->d_cnt, e->staging, e->slab_boot,
@@ -1043,6 +1052,8 @@ static int eager_discard(ngd_engine *e) {
   return NGD_OK;
 }
 
+static int stage_slots(ngd_engine *e);
+
 static int stage_init(ngd_engine *e) {
   if (e->pin_sites) return NGD_OK;
   stage_reap(e);
@@ -1053,7 +1064,9 @@ static int stage_init(ngd_engine *e) {
   if (!e->st_copy[0]) HIPCHK(hipStreamCreateWithFlags(&e->st_copy[0], hipStreamNonBlocking));
   e->n_staged = 0;
   e->pin_cur = 0;
-  return e->d_nan ? NGD_OK : dev_alloc(e, &e->d_nan, 1, true);
+  if (!e->d_nan)
+    if (int rc = dev_alloc(e, &e->d_nan, 1, true)) return rc;
+  return stage_slots(e);
 }
 
 // A pinned buffer of the ring comes from hipHostMalloc (which allocates, zeroes and pins 4-KB pages at ~6.5 GiB/s: 5 ms per
@@ -1071,15 +1084,40 @@ static void pin_release(double *p) {
   if (p) (void)hipHostFree(p);
 }
 
-static int stage_slot(ngd_engine *e, int b) {
-  if (e->pin[b]) return NGD_OK;
+// every slot's device twin and events at once (cheap); pinned buffer 0 at once, the others by ring_maker
+static int stage_slots(ngd_engine *e) {
   const uint64_t bytes = e->pin_sites * e->g.n_ind * 24;
-  if (int rc = pin_alloc(e, b, bytes)) return rc;
-  int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
-  if (rc) return rc;
-  HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&e->k0_done[b], hipEventDisableTiming));
+  for (int b = 0; b < e->ring_slots; b++) {
+    int rc = dev_alloc(e, &e->draw[b], bytes / 8, false);
+    if (rc) return rc;
+    HIPCHK(hipEventCreateWithFlags(&e->pin_free[b], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->k0_done[b], hipEventDisableTiming));
+  }
+  if (int rc = pin_alloc(e, 0, bytes)) return rc;
+  e->ring_ready = 1;
+  e->ring_stop = false;
+  e->ring_maker_rc = 0;
+  if (e->ring_slots > 1) {
+    const int dev = e->device, n = e->ring_slots;
+    e->ring_maker = std::thread([e, dev, n, bytes]() {
+      if (hipSetDevice(dev) != hipSuccess) { e->ring_maker_rc = NGD_E_HIP; return; }
+      for (int b = 1; b < n && !e->ring_stop.load(std::memory_order_relaxed); b++) {
+        if (hipHostMalloc((void **)&e->pin[b], bytes, hipHostMallocDefault) != hipSuccess) {  // (the load goes on with the buffers it has)
+          e->pin[b] = nullptr;
+          (void)hipGetLastError();
+          e->ring_maker_rc = NGD_E_NOMEM;
+          return;
+        }
+        e->ring_ready.store(b + 1, std::memory_order_release);
+      }
+    });
+  }
   return NGD_OK;
+}
+
+static void ring_maker_join(ngd_engine *e) {
+  e->ring_stop = true;
+  if (e->ring_maker.joinable()) e->ring_maker.join();
 }
 
 int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites) {
@@ -1089,8 +1127,6 @@ int ngd_stage_acquire(ngd_engine *e, double **host_buf, uint64_t *capacity_sites
   int rc = stage_init(e);
   if (rc) return rc;
   const int b = e->pin_cur;
-  rc = stage_slot(e, b);
-  if (rc) return rc;
   // the copy out of this buffer, a turn of the ring ago, is done -- and so is the preparation kernel that read its device
   // twin (it follows the copy on the engine's stream, ~30 us): waited for HERE, on the host, so that the copy stream carries
   // no wait of its own ([measured] a stream-side wait on an event costs the copy engine ~50 us of idling per copy)
@@ -1123,7 +1159,7 @@ int ngd_stage_submit(ngd_engine *e, uint64_t s0, uint64_t n, const ngd_prep *pre
   HIPCHK(hipEventRecord(e->k0_done[b], e->st));
   if (int rc = eager_advance(e, s0, n, b)) return rc;
   e->pin_lent = -1;
-  e->pin_cur = (b + 1) % e->ring_slots;
+  e->pin_cur = (b + 1) % std::max(1, e->ring_ready.load(std::memory_order_acquire));  // (the buffers that exist by now)
   return NGD_OK;
 }
 
@@ -1151,6 +1187,7 @@ int ngd_commit(ngd_engine *e) {
   if (e->d_nan) {
     int flag = 0;
     HIPCHK(hipMemcpy(&flag, e->d_nan, sizeof(int), hipMemcpyDeviceToHost));
+    ring_maker_join(e);
     {  // the pipeline is over: its buffers go back on a thread of their own (6 x hipHostFree + hipFree are ~30 ms)
       struct Slot { double *pin, *draw; hipEvent_t a, b; };
       std::vector<Slot> slots;
@@ -1161,6 +1198,7 @@ int ngd_commit(ngd_engine *e) {
       }
       e->pin_sites = 0;
       e->ring_slots = 0;
+      e->ring_ready = 0;
       stage_reap(e);
       const int dev = e->device;
       if (!slots.empty())
