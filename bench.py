@@ -160,6 +160,11 @@ def main():
                     help="--pairwise_del with --miss_frac missing sites: counts differ per pair, so the N>1 flow also "
                          "reduce-scatters the valid-site counts (not a BASELINE configuration)")
     ap.add_argument("--miss_frac", type=float, default=0.0, help="fraction of exact (1/3,1/3,1/3) sites in the input")
+    ap.add_argument("--split_tail", action="store_true",
+                    help="N = 1 bootstrap jobs: the round-5 form of a job's tail -- the engine call ends when the sums are in "
+                         "device memory, THEN they are copied out in chunks and ngd_finish_stream works them -- instead of "
+                         "ngd_run_mult_batch_dist (groups of replicates copied out while the later ones are reduced, the tail "
+                         "inside the call)")
     ap.add_argument("--serial_tail", action="store_true",
                     help="only the headline region (one job at a time: a job's tail -- copy out, /cnt, evolutionary model; "
                          "N > 1: the collectives too -- ends before the next job's kernels start); skip the second, "
@@ -411,6 +416,12 @@ def main():
         fold0 = n_eff == n_sites
         rows = ([np.ones(n_blocks, dtype=np.uint32)] if fold0 else []) + mults[1:]
         mult_all = np.ascontiguousarray(np.stack(rows)[:, blk_lo:blk_hi] if by_sites else np.stack(rows))
+    one_call = (batched and world == 1 and not by_reps and fold0 and not zero_copy and not args.split_tail and not args.vary_jobs)
+    if one_call:
+        import ctypes as C
+        assert mult_all.shape == (n_mat, n_blocks) and mult_all.dtype == np.uint32 and dist_all.flags.c_contiguous
+        one_args = (eng._h, mult_all.ctypes.data_as(C.POINTER(C.c_uint32)), n_mat, n_blocks, int(W["block"]), 0, int(W["evol_model"]),
+                    dist_all.ctypes.data_as(C.POINTER(C.c_double)), mult_all, dist_all)
 
     # --vary_jobs: the other job (odd steps counted from the END of a region, so that a region's last step is the
     # workload's own job and the spot check below applies to it)
@@ -492,6 +503,15 @@ def main():
         if tail_job[buf] is not None:  # the job that used this set of buffers two steps ago has left them
             tail_job[buf].result()
         da, dc = d_flat_b[buf][:total].view(n_mat, n_pairs), d_cflat_b[buf][:total].view(n_mat, n_pairs)
+        if one_call and mode["serial"] and not variant:
+            # the job and its tail in ONE call of the C ABI: a group of replicates leaves the device as soon as it is reduced
+            # and the host's threads finish each chunk as it lands (engine.hip run_dist)
+            if L_abi.ngd_run_mult_batch_dist(*one_args[:8]) != 0:
+                raise RuntimeError("ngd_run_mult_batch_dist: " + L_abi.ngd_last_error().decode())
+            if record:
+                record_timing()
+            last["dist"] = dist_all[-1]
+            return
         if batched:
             first = 0 if fold0 else 1
             if not fold0:
@@ -1013,7 +1033,10 @@ def main():
                    "results": ("written by the reduction kernel straight into pinned host memory (mapped into the device's "
                                "address space): no separate copy" if world == 1 and not by_reps and zero_copy else
                                "device buffers, copied to pinned host memory"),
-                   "host_tail": "serial: a job's copy-out and ngd_finish (N > 1: the collectives too) end before the next "
+                   "host_tail": ("inside the engine call (ngd_run_mult_batch_dist): a group of 32 replicates is copied out as soon "
+                                 "as it is reduced, beside the later groups' reductions, and the host's threads finish each "
+                                 "chunk as it lands; " if one_call else "") +
+                                "serial: a job's copy-out and ngd_finish (N > 1: the collectives too) end before the next "
                                 "job's kernels start -- ms_per_step and value are ONE job's latency",
                    "pair_sites_per_s": n_pairs * float(n_eff if W["n_boot"] else n_sites) * n_mat * args.steps / dt,
                    "sharding": ("site axis split over %d ranks (each holds 1/%d of the data, all pairs): one RCCL "

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,29 @@ struct ngd_engine {
   unsigned long long *d_bcnt = nullptr;
   uint64_t cap_batch = 0;
   uint32_t n_batch_valid = 0;  // matrices of the last batch / job call, still in d_bsum / d_bcnt (ngd_fetch_matrix)
+  // ngd_run_job_dist / ngd_run_mult_batch_dist: the matrices of d_bsum / d_bcnt leave the device in chunks on a stream
+  // of their own -- in the per-block-partials plan a group of replicates as soon as its reduction is over, beside the
+  // reductions of the later groups -- into pinned memory of the engine's, and the tail of gen_dist() (host_util.cpp) works
+  // the cells of a chunk as soon as it has landed
+  struct OutStream {
+    bool on = false, pdel = false;
+    hipStream_t st = nullptr, st2 = nullptr;  // chunks alternate between two copy streams
+    uint32_t n_chunk_seq = 0, n_landed = 0;    // chunks queued / declared landed so far in this call
+    double *h_sum = nullptr;
+    uint64_t *h_cnt = nullptr;
+    uint64_t cap_sum = 0, cap_cnt = 0;       // cells
+    uint32_t n_mat = 0, queued = 0;          // matrices of this call; matrices [0, queued) have their copies on st
+    std::vector<hipEvent_t> pool;            // events, made on demand and kept
+    uint32_t n_used = 0;
+    std::vector<std::pair<hipEvent_t, uint32_t>> chunks;  // (the copy's event, matrices in host memory once it has happened)
+    std::vector<uint64_t> cnt_mat;           // no --pairwise_del: a matrix's count (the sites it visits), ngsDist.cpp:362
+    uint64_t evol_model = 0, tot_sites = 0;  // tot_sites > 0: the count of every cell (ngsDist.cpp:372-373)
+    double *dist = nullptr;
+    volatile uint64_t landed = 0;            // cells of h_sum (h_cnt) that are final: raised by the calling thread
+    std::thread finisher;
+    int finisher_rc = 0;
+    double t0 = 0, t_call = 0;  // NGD_TRACE_OUT
+  } out;
   double *staging = nullptr;
   uint64_t staging_sites = 0;
   // raw-input pipeline: a ring of pinned host buffers, each with its device buffer; the copies run on a stream of
@@ -461,6 +485,11 @@ void ngd_destroy(ngd_engine *e) {
     if (e->st_copy[c]) hipStreamDestroy(e->st_copy[c]);
   if (e->st_eager) hipStreamDestroy(e->st_eager);
   if (e->ev_eager) hipEventDestroy(e->ev_eager);
+  if (e->out.st) { hipStreamSynchronize(e->out.st); hipStreamDestroy(e->out.st); }
+  if (e->out.st2) { hipStreamSynchronize(e->out.st2); hipStreamDestroy(e->out.st2); }
+  for (hipEvent_t v : e->out.pool) hipEventDestroy(v);
+  if (e->out.h_sum) hipHostFree(e->out.h_sum);
+  if (e->out.h_cnt) hipHostFree(e->out.h_cnt);
   if (e->h_clk) hipHostFree(e->h_clk);
   if (e->h_fixcount) hipHostFree(e->h_fixcount);
   if (e->d_nan) hipFree(e->d_nan);
@@ -1676,6 +1705,144 @@ static int pass_impl(ngd_engine *e, const uint32_t *mult, uint32_t mult_max, uin
 // for the valid-site counts).  One accumulation pass fills S_b; replicates are then weighted reductions of
 // the partials, up to 32 per pass over them.  MFMA slices are whole k-groups of 4 contraction indices, so
 // blocks must be multiples of 4 sites there.  *feasible = false: the caller falls back to pass_impl().
+// ---- a job's matrices leaving the device while later ones are still being reduced (ngd_run_job_dist) ----
+static bool out_trace() {
+  static const bool on = getenv("NGD_TRACE_OUT") != nullptr;
+  return on;
+}
+static double out_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int out_event(ngd_engine *e, hipEvent_t *ev) {
+  auto &o = e->out;
+  if (o.n_used == o.pool.size()) {
+    hipEvent_t v;
+    HIPCHK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+    o.pool.push_back(v);
+  }
+  *ev = o.pool[o.n_used++];
+  return NGD_OK;
+}
+
+// The copies of matrices [queued, m_hi) of d_bsum (--pairwise_del: and d_bcnt) are queued behind whatever the engine's stream
+// holds NOW (the first event of a call is the first gate: partials_impl waits for it before it wakes the host's threads):
+// chunks of about 8 MiB with an event each, alternating between two copy streams (a chunk's set-up and its event then hide
+// behind the other stream's transfer: 49 -> 55 GB/s at cfg 5), tapering towards the job's end -- a chunk is at most a quarter
+// of what is left -- because what the host's threads still have to do once the last byte has landed is the last chunk's cells.
+// ([measured, round 6] a kernel pushing the results into the pinned buffers 64 KiB at a time with a flag in host memory
+// behind every piece -- no events, a smooth arrival -- was no faster, 50 GB/s, and slowed the reductions it ran beside.)
+static int out_queue(ngd_engine *e, uint32_t m_hi) {
+  auto &o = e->out;
+  if (!o.on || m_hi <= o.queued) return NGD_OK;
+  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
+  hipEvent_t gate;
+  if (int rc = out_event(e, &gate)) return rc;
+  HIPCHK(hipEventRecord(gate, e->st));
+  HIPCHK(hipStreamWaitEvent(o.st, gate, 0));
+  HIPCHK(hipStreamWaitEvent(o.st2, gate, 0));
+  const uint32_t step = (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1, (8ull << 20) / std::max<uint64_t>(1, n_pairs * 8)));
+  for (uint32_t a = o.queued, b; a < m_hi; a = b) {
+    b = std::min(m_hi, a + std::min(step, std::max(1u, (o.n_mat - a + 3) / 4)));
+    hipStream_t st = (o.n_chunk_seq++ & 1) ? o.st2 : o.st;
+    HIPCHK(hipMemcpyAsync(o.h_sum + (uint64_t)a * n_pairs, e->d_bsum + (uint64_t)a * n_pairs, (uint64_t)(b - a) * n_pairs * sizeof(double),
+                          hipMemcpyDeviceToHost, st));
+    if (o.pdel)
+      HIPCHK(hipMemcpyAsync(o.h_cnt + (uint64_t)a * n_pairs, e->d_bcnt + (uint64_t)a * n_pairs, (uint64_t)(b - a) * n_pairs * sizeof(uint64_t),
+                            hipMemcpyDeviceToHost, st));
+    hipEvent_t ev;
+    if (int rc = out_event(e, &ev)) return rc;
+    HIPCHK(hipEventRecord(ev, st));
+    o.chunks.emplace_back(ev, b);
+  }
+  o.queued = m_hi;
+  return NGD_OK;
+}
+
+static void out_declare(ngd_engine *e, uint64_t cells) {
+  auto &o = e->out;
+  std::atomic_thread_fence(std::memory_order_release);
+  o.landed = cells;
+  if (out_trace()) fprintf(stderr, "[out] %.2f matrices landed +%.3f\n", (double)cells / (double)ngd_n_pairs(e->g.n_ind), out_now() - o.t0);
+}
+
+// Declares landed whatever has arrived since the last look (never waits)
+static int out_advance(ngd_engine *e) {
+  auto &o = e->out;
+  while (o.n_landed < o.chunks.size()) {
+    const hipError_t q = hipEventQuery(o.chunks[o.n_landed].first);
+    if (q == hipErrorNotReady) break;
+    HIPCHK(q);
+    out_declare(e, (uint64_t)o.chunks[o.n_landed].second * ngd_n_pairs(e->g.n_ind));
+    o.n_landed++;
+  }
+  return NGD_OK;
+}
+
+// What has been queued carries sums that a fix-up pass is about to replace
+static int out_join(ngd_engine *e, int rc);
+static int out_requeue(ngd_engine *e) {
+  auto &o = e->out;
+  if (!o.on) return NGD_OK;
+  HIPCHK(hipStreamSynchronize(o.st));
+  HIPCHK(hipStreamSynchronize(o.st2));
+  // pieces may have been declared landed already (partials_impl lands what arrives while the last groups are reduced): the
+  // host's threads are let through the stale cells and start again from nothing once the matrices have been reduced again
+  if (int rc = out_join(e, NGD_OK)) return rc;
+  o.on = true;
+  o.landed = 0;
+  o.n_landed = 0;
+  o.queued = 0;
+  o.chunks.clear();
+  return NGD_OK;
+}
+
+static void out_start_finisher(ngd_engine *e) {
+  auto &o = e->out;
+  if (!o.on || o.finisher.joinable()) return;
+  o.finisher_rc = 0;
+  if (o.tot_sites) o.cnt_mat.assign(o.n_mat, o.tot_sites);
+  const uint64_t n_pairs = ngd_n_pairs(e->g.n_ind);
+  o.finisher = std::thread([e, n_pairs]() {
+    auto &q = e->out;
+    q.finisher_rc = ngd_finish_matrices_stream(q.h_sum, q.pdel ? q.h_cnt : nullptr, q.pdel ? nullptr : q.cnt_mat.data(), q.n_mat, n_pairs,
+                                               q.evol_model, q.dist, &q.landed);
+  });
+}
+
+// The end of a streamed call, good or bad: the host's threads are let through whatever is left (after a failure: over
+// cells nobody will read) and joined.
+static int out_join(ngd_engine *e, int rc) {
+  auto &o = e->out;
+  if (o.finisher.joinable()) {
+    std::atomic_thread_fence(std::memory_order_release);
+    o.landed = (uint64_t)o.n_mat * ngd_n_pairs(e->g.n_ind);
+    o.finisher.join();
+    if (!rc && o.finisher_rc) rc = fail(o.finisher_rc, "ngd_run_*_dist: the tail of gen_dist() failed");
+  }
+  o.on = false;
+  return rc;
+}
+
+static int out_land_all(ngd_engine *e) {
+  auto &o = e->out;
+  for (; o.n_landed < o.chunks.size(); o.n_landed++) {
+    HIPCHK(hipEventSynchronize(o.chunks[o.n_landed].first));
+    out_declare(e, (uint64_t)o.chunks[o.n_landed].second * ngd_n_pairs(e->g.n_ind));
+  }
+  return NGD_OK;
+}
+
+static int out_land(ngd_engine *e) {
+  auto &o = e->out;
+  int rc = out_queue(e, o.n_mat);
+  if (!rc) {
+    out_start_finisher(e);
+    rc = out_land_all(e);
+  }
+  rc = out_join(e, rc);
+  if (out_trace()) fprintf(stderr, "[out] tail joined +%.3f\n", out_now() - o.t0);
+  return rc;
+}
+
 static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]*/, const unsigned long long *drawn,
                          uint32_t n_rep, uint64_t n_blocks, uint64_t block_size, double *d_sum,
                          unsigned long long *d_cnt, bool *feasible) {
@@ -1743,6 +1910,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     }
   }
   *feasible = true;
+  if (e->out.on && out_trace()) fprintf(stderr, "[out] plan settled %.3f ms into the call\n", out_now() - e->out.t_call);
 
   HIPCHK(hipEventRecord(e->ev[0], e->st));
   uint32_t launches = 0;
@@ -1801,43 +1969,106 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     HIPCHK(hipMemsetAsync(e->d_fixseen, 0, (n_pairs / 32 + 1) * sizeof(uint32_t), e->st));
   }
   const bool fix_in_reduce = fix && !pdel;  // (--pairwise_del: noted once the counts are known, below)
-  ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum,
-                      fix_in_reduce ? &ff : nullptr, e->d_fixthr);
-  if (fix_in_reduce) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e->ev[3], e->st));
-
   std::vector<uint32_t> M;
-  if (pdel) {
-    if (!c_cached) {
-      e->cnt_B = 0;
-      rc = ensure_cap(e, &e->cnt_boot, &e->cnt_boot_elems, c_elems);
+  // ngd_run_*_dist, the job's first matrix at the head of d_bsum: a group of replicates is reduced by a launch of its own
+  // and its copy to the host queued behind it, so that the copies run beside the later groups' reductions
+  const bool stream_out = e->out.on && d_sum == e->d_bsum && d_cnt == e->d_bcnt && e->out.queued == 0;
+  if (stream_out) {
+    // the counts' inputs first: they do not depend on the sums
+    if (pdel) {
+      if (!c_cached) {
+        e->cnt_B = 0;
+        rc = ensure_cap(e, &e->cnt_boot, &e->cnt_boot_elems, c_elems);
+        if (rc) return rc;
+        ngd_launch_count_blocks(e->st, g, e->mask, block_size, (uint32_t)n_blocks, e->d_tiles16, e->n_tiles16, e->cnt_boot);
+        HIPCHK(hipGetLastError());
+        e->cnt_B = block_size;
+        e->cnt_blocks = n_blocks;
+      }
+      M.assign(n_blocks * stride, 0u);
+      for (uint32_t r = 0; r < n_rep; r++)
+        for (uint64_t b = 0; b < n_blocks; b++) M[b * stride + r] = mult[(uint64_t)r * n_blocks + b];
+      rc = ensure_cap(e, &e->d_M, &e->cap_M, M.size());
       if (rc) return rc;
-      ngd_launch_count_blocks(e->st, g, e->mask, block_size, (uint32_t)n_blocks, e->d_tiles16, e->n_tiles16, e->cnt_boot);
-      HIPCHK(hipGetLastError());
-      e->cnt_B = block_size;
-      e->cnt_blocks = n_blocks;
+      HIPCHK(hipMemcpyAsync(e->d_M, M.data(), M.size() * 4, hipMemcpyHostToDevice, e->st));
+    } else {
+      rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_rep);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(e->d_drawn, drawn, (uint64_t)n_rep * 8, hipMemcpyHostToDevice, e->st));
+      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, 0, e->d_drawn, n_rep, d_cnt);
     }
-    M.assign(n_blocks * stride, 0u);
-    for (uint32_t r = 0; r < n_rep; r++)
-      for (uint64_t b = 0; b < n_blocks; b++) M[b * stride + r] = mult[(uint64_t)r * n_blocks + b];
-    rc = ensure_cap(e, &e->d_M, &e->cap_M, M.size());
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_M, M.data(), M.size() * 4, hipMemcpyHostToDevice, e->st));
-    ngd_launch_reduce_c(e->st, g, e->cnt_boot, (uint32_t)n_blocks, e->d_M, stride, n_rep, e->d_tiles, e->n_tiles, d_cnt);
-    if (fix) {
-      ngd_launch_fix_flag(e->st, g, d_sum, d_cnt, n_rep, e->d_tiles, e->n_tiles, ff);
-      HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    const uint32_t rb = ngd_reduce_chunk(n_rep);
+    for (uint32_t r0 = 0; r0 < n_rep; r0 += rb) {
+      const uint32_t n = std::min(rb, n_rep - r0);
+      ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W + r0, stride, n, e->d_tiles, e->n_tiles,
+                          d_sum + (uint64_t)r0 * n_pairs, fix_in_reduce ? &ff : nullptr, e->d_fixthr ? e->d_fixthr + r0 : nullptr, rb);
+      if (r0 + rb >= n_rep) HIPCHK(hipEventRecord(e->ev[3], e->st));
+      if (pdel)
+        ngd_launch_reduce_c(e->st, g, e->cnt_boot, (uint32_t)n_blocks, e->d_M + r0, stride, n, e->d_tiles, e->n_tiles,
+                            d_cnt + (uint64_t)r0 * n_pairs, rb);
+      HIPCHK(hipGetLastError());
+      if ((rc = out_queue(e, r0 + n))) return rc;
+    }
+    if (fix && pdel) ngd_launch_fix_flag(e->st, g, d_sum, d_cnt, n_rep, e->d_tiles, e->n_tiles, ff);
+    if (fix) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[4], e->st));
+    // the host's threads are woken once the first group has been reduced: its first chunk is about to land
+    const double t_q = out_now();
+    HIPCHK(hipEventSynchronize(e->out.pool[0]));
+    const double t_g = out_now();
+    out_start_finisher(e);
+    if (out_trace()) fprintf(stderr, "[out] queued %.3f ms into the call, first group reduced +%.3f ms, finisher started +%.3f\n", t_q - e->out.t_call, t_g - t_q, out_now() - t_q);
+    e->out.t0 = t_q;
+    // ... and chunks are declared landed as they arrive while the later groups are still being reduced -- before it is known
+    // whether the fix-up pass will patch the partial results (it rarely does: then every matrix is copied and finished again)
+    for (;;) {
+      const hipError_t q = hipEventQuery(e->ev[4]);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) HIPCHK(q);
+      if ((rc = out_advance(e))) return rc;
+      __builtin_ia32_pause();
     }
   } else {
-    rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_rep);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_drawn, drawn, (uint64_t)n_rep * 8, hipMemcpyHostToDevice, e->st));
-    ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, 0, e->d_drawn, n_rep, d_cnt);
+    ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum,
+                        fix_in_reduce ? &ff : nullptr, e->d_fixthr);
+    if (fix_in_reduce) HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev[3], e->st));
+
+    if (pdel) {
+      if (!c_cached) {
+        e->cnt_B = 0;
+        rc = ensure_cap(e, &e->cnt_boot, &e->cnt_boot_elems, c_elems);
+        if (rc) return rc;
+        ngd_launch_count_blocks(e->st, g, e->mask, block_size, (uint32_t)n_blocks, e->d_tiles16, e->n_tiles16, e->cnt_boot);
+        HIPCHK(hipGetLastError());
+        e->cnt_B = block_size;
+        e->cnt_blocks = n_blocks;
+      }
+      M.assign(n_blocks * stride, 0u);
+      for (uint32_t r = 0; r < n_rep; r++)
+        for (uint64_t b = 0; b < n_blocks; b++) M[b * stride + r] = mult[(uint64_t)r * n_blocks + b];
+      rc = ensure_cap(e, &e->d_M, &e->cap_M, M.size());
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(e->d_M, M.data(), M.size() * 4, hipMemcpyHostToDevice, e->st));
+      ngd_launch_reduce_c(e->st, g, e->cnt_boot, (uint32_t)n_blocks, e->d_M, stride, n_rep, e->d_tiles, e->n_tiles, d_cnt);
+      if (fix) {
+        ngd_launch_fix_flag(e->st, g, d_sum, d_cnt, n_rep, e->d_tiles, e->n_tiles, ff);
+        HIPCHK(hipMemcpyAsync(e->h_fixcount, e->d_fixcount, sizeof(uint32_t), hipMemcpyDeviceToHost, e->st));
+      }
+    } else {
+      rc = ensure_cap(e, &e->d_drawn, &e->cap_drawn, (uint64_t)n_rep);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(e->d_drawn, drawn, (uint64_t)n_rep * 8, hipMemcpyHostToDevice, e->st));
+      ngd_launch_fill_cnt(e->st, g, e->d_tiles, e->n_tiles, 0, e->d_drawn, n_rep, d_cnt);
+    }
+
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e->ev[4], e->st));
+  if (!stream_out) HIPCHK(hipEventRecord(e->ev[4], e->st));
   HIPCHK(hipStreamSynchronize(e->st));  // W, M, drawn are host temporaries
+  if (stream_out && out_trace()) fprintf(stderr, "[out] engine stream drained +%.3f\n", out_now() - e->out.t0);
   read_timing(e, n_eff, launches, false);
   if ((rc = mfma_fault(e))) return rc;
   if (fix) {  // the noted pairs' partial results exactly, then the replicates again from the patched slab
@@ -1845,6 +2076,7 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
     rc = fixup_pass(e, nullptr, n_eff, nullptr, block_size / sub, (uint32_t)n_slices, &patched);
     if (rc) return rc;
     if (patched) {
+      if (stream_out && (rc = out_requeue(e))) return rc;  // (what has been copied so far: sums from before the patch)
       ngd_launch_reduce_w(e->st, g, e->slab_boot, (uint32_t)n_slices, e->d_W, stride, n_rep, e->d_tiles, e->n_tiles, d_sum);
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(e->st));
@@ -2157,6 +2389,7 @@ static int run_impl(ngd_engine *e, const uint64_t *block_maps, const uint32_t *m
     drawn[0] = g.n_sites;
     mult_max[0] = 1;
   }
+  if (e->out.on) e->out.cnt_mat.assign(drawn.begin(), drawn.end());  // (no --pairwise_del: a matrix's count, every pair's)
   double *rep_sum = d_sum + (uint64_t)lead * n_pairs;
   unsigned long long *rep_cnt = d_cnt + (uint64_t)lead * n_pairs;
 
@@ -2324,6 +2557,72 @@ int ngd_run_job(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint6
   rc = run_impl(e, block_maps, nullptr, n_rep, n_rep != 0, n_blocks, block_size, e->d_bsum, e->d_bcnt);
   if (rc) return rc;
   return copy_out(e, n_rep + 1, e->d_bsum, e->d_bcnt, sum, cnt);
+}
+
+// A whole job AND the tail of gen_dist() (ngsDist.cpp:372-401) in one call: the sums (and, --pairwise_del, the counts) leave
+// the device chunk by chunk on a stream of their own into pinned memory of the engine's while -- in the per-block-partials
+// plan -- later groups of replicates are still being reduced, and the host's threads turn each chunk into distances as it
+// lands.  The matrices stay in the engine as after ngd_run_job(..., NULL, NULL) (ngd_fetch_matrix).
+static int run_dist(ngd_engine *e, const uint64_t *block_maps, const uint32_t *mult, uint32_t n_rep, bool lead_full,
+                    uint64_t n_blocks, uint64_t block_size, uint64_t tot_sites, uint64_t evol_model, double *dist, const char *who) {
+  if (!e || !dist) return fail(NGD_E_INVALID, std::string(who) + ": null argument");
+  if (tot_sites && e->cfg.pairwise_del)
+    return fail(NGD_E_INVALID, std::string(who) + ": a total number of sites cannot go with pairwise deletion (parse_args.cpp:209-210)");
+  if (evol_model > 2) return fail(NGD_E_MODEL, std::string(who) + ": evolutionary model not supported (ngsDist.cpp:398-399)");
+  if (e->cfg.shard_world > 1)
+    return fail(NGD_E_INVALID, std::string(who) + ": an engine that owns a share of the pairs holds part of every matrix -- put the "
+                               "shares together first (ngd_run_job_device + the ranks' exchange), then ngd_finish()");
+  if (!e->committed) return fail(NGD_E_INVALID, std::string(who) + ": call ngd_commit() first");
+  const double t_enter = out_now();
+  HIPCHK(hipSetDevice(e->device));
+  const uint32_t n_mat = n_rep ? n_rep + (lead_full ? 1u : 0u) : 1u;
+  int rc = batch_buffers(e, n_mat);
+  if (rc) return rc;
+  auto &o = e->out;
+  const uint64_t cells = (uint64_t)n_mat * ngd_n_pairs(e->g.n_ind);
+  if (!o.st) HIPCHK(hipStreamCreateWithFlags(&o.st, hipStreamNonBlocking));
+  if (!o.st2) HIPCHK(hipStreamCreateWithFlags(&o.st2, hipStreamNonBlocking));
+  if (cells > o.cap_sum) {
+    if (o.h_sum) { HIPCHK(hipHostFree(o.h_sum)); o.h_sum = nullptr; o.cap_sum = 0; }
+    HIPCHK(hipHostMalloc((void **)&o.h_sum, std::max<uint64_t>(1, cells) * sizeof(double), hipHostMallocDefault));
+    o.cap_sum = cells;
+  }
+  o.pdel = e->cfg.pairwise_del != 0;
+  if (o.pdel && cells > o.cap_cnt) {
+    if (o.h_cnt) { HIPCHK(hipHostFree(o.h_cnt)); o.h_cnt = nullptr; o.cap_cnt = 0; }
+    HIPCHK(hipHostMalloc((void **)&o.h_cnt, std::max<uint64_t>(1, cells) * sizeof(uint64_t), hipHostMallocDefault));
+    o.cap_cnt = cells;
+  }
+  o.n_mat = n_mat;
+  o.queued = 0;
+  o.n_used = 0;
+  o.n_chunk_seq = 0;
+  o.n_landed = 0;
+  o.chunks.clear();
+  o.landed = 0;
+  o.evol_model = evol_model;
+  o.tot_sites = tot_sites;
+  o.dist = dist;
+  o.cnt_mat.assign(n_mat, e->g.n_sites);  // (a plain pass; a job's run_impl writes its matrices' own)
+  o.on = true;
+  o.t_call = out_now();
+  rc = run_impl(e, block_maps, mult, n_rep, n_rep && lead_full, n_blocks, block_size, e->d_bsum, e->d_bcnt);
+  rc = rc ? out_join(e, rc) : out_land(e);
+  if (!rc) e->n_batch_valid = n_mat;
+  if (out_trace()) fprintf(stderr, "[out] call: %.3f ms (setup before it %.3f)\n", out_now() - o.t_call, o.t_call - t_enter);
+  return rc;
+}
+
+int ngd_run_job_dist(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                     uint64_t tot_sites, uint64_t evol_model, double *dist) {
+  if (n_rep && !block_maps) return fail(NGD_E_INVALID, "ngd_run_job_dist: null argument");
+  return run_dist(e, block_maps, nullptr, n_rep, true, n_blocks, block_size, tot_sites, evol_model, dist, "ngd_run_job_dist");
+}
+
+int ngd_run_mult_batch_dist(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                            uint64_t tot_sites, uint64_t evol_model, double *dist) {
+  if (!mult || !n_rep) return fail(NGD_E_INVALID, "ngd_run_mult_batch_dist: null argument");
+  return run_dist(e, nullptr, mult, n_rep, false, n_blocks, block_size, tot_sites, evol_model, dist, "ngd_run_mult_batch_dist");
 }
 
 int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt) {

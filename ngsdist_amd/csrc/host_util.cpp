@@ -4,6 +4,7 @@
 // draw (ngsDist.cpp:416-423 over gsl_rng_taus, seeded at :179-180).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -448,3 +449,53 @@ int ngd_finish_stream(const double *sum, const uint64_t *cnt, uint64_t n_pairs, 
 }
 
 }  // extern "C"
+
+// The same for the engine's own use (engine.hip run_dist: a job's tail inside the call), over n_mat matrices of n_pairs cells:
+// the counts per cell (cnt), or -- without --pairwise_del, where every pair of a matrix has the same count, ngsDist.cpp:362 --
+// one per matrix (cnt_mat), so that no array of counts has to leave the device.  The division is the reference's either
+// way (sum / (double)count).
+int ngd_finish_matrices_stream(const double *sum, const uint64_t *cnt, const uint64_t *cnt_mat, uint32_t n_mat, uint64_t n_pairs,
+                               uint64_t evol_model, double *dist, const volatile uint64_t *landed) {
+  if (evol_model > 2) return NGD_E_MODEL;
+  if (!sum || (!cnt && !cnt_mat) || !dist || !landed) return NGD_E_INVALID;
+  const uint64_t total = (uint64_t)n_mat * n_pairs;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const bool wide = total >= (1u << 19) && hw > 16;
+  const unsigned nt = wide ? std::min(64u, hw) : std::min(16u, hw);
+  // shares of 4096 cells (finish_range's own grain): the cells of the LAST chunk to land are then spread over all the threads
+  const unsigned parts = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, total / 4096), 1u << 20);
+  const uint64_t per = (total + parts - 1) / parts;
+  auto share = [&](unsigned k) {
+    const uint64_t lo = (uint64_t)k * per, hi = std::min(total, lo + per);
+    if (lo >= hi) return;
+    for (unsigned spins = 0; *landed < hi; spins++) {  // (the engine may be recomputing noted pairs meanwhile: then sleep)
+      if (spins < 4096) __builtin_ia32_pause();  // (~0.1 ms; the threads' CPU time counts against the process's quota)
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (cnt) {
+      finish_range(sum, cnt, lo, hi, 0, evol_model, dist);
+      return;
+    }
+    for (uint64_t a = lo; a < hi;) {  // matrix by matrix: one count each
+      const uint64_t m = a / n_pairs, b = std::min(hi, (m + 1) * n_pairs);
+      if (cnt_mat[m]) {
+        finish_range(sum, nullptr, a, b, cnt_mat[m], evol_model, dist);
+      } else {  // (a matrix that visits no site: 0 / 0 as the per-cell form has it)
+        const uint64_t zero = 0;
+        for (uint64_t c = a; c < b; c++) finish_range(sum + c, &zero, 0, 1, 0, evol_model, dist + c);
+      }
+      a = b;
+    }
+  };
+  if (nt <= 1 || parts <= 1) {
+    for (unsigned k = 0; k < parts; k++) share(k);
+  } else {
+    // the shares are dealt by a counter of their own, in ascending order (the pool's mutex per part would cost more than a share)
+    std::atomic<unsigned> next{0};
+    (wide ? host_pool_wide() : host_pool()).run(std::min(nt, parts), [&](unsigned) {
+      for (unsigned k; (k = next.fetch_add(1, std::memory_order_relaxed)) < parts;) share(k);
+    });
+  }
+  return NGD_OK;
+}

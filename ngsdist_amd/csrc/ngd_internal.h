@@ -253,14 +253,17 @@ void ngd_launch_fix_merge(hipStream_t st, const ngd_geom &g, const double *d_new
                           double thr, const ngd_tile *d_tiles, uint32_t n_tiles);
 void ngd_launch_fix_flag(hipStream_t st, const ngd_geom &g, const double *d_sum, const unsigned long long *d_cnt,
                          uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles, const ngd_fix_flags &fix);
+// host_util.cpp: ngd_finish_stream over n_mat matrices, counts per cell (cnt) or one per matrix (cnt_mat)
+int ngd_finish_matrices_stream(const double *sum, const uint64_t *cnt, const uint64_t *cnt_mat, uint32_t n_mat, uint64_t n_pairs,
+                               uint64_t evol_model, double *dist, const volatile uint64_t *landed);
 uint32_t ngd_reduce_chunk(uint32_t n_rep);  // replicates per pass; weight strides are multiples of it
 // fix != NULL: a pair is noted if its sum in ANY replicate r is below d_thr[r]
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         double *d_sum, const ngd_fix_flags *fix = nullptr, const double *d_thr = nullptr);
+                         double *d_sum, const ngd_fix_flags *fix = nullptr, const double *d_thr = nullptr, uint32_t chunk = 0);
 void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
                          uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         unsigned long long *d_cnt);
+                         unsigned long long *d_cnt, uint32_t chunk = 0);
 void ngd_launch_count_blocks(hipStream_t st, const ngd_geom &g, const unsigned long long *mask, uint64_t block_size,
                              uint32_t n_blocks, const ngd_tile *d_tiles16, uint32_t n_tiles16, uint32_t *C);
 void ngd_launch_count(hipStream_t st, const ngd_geom &g, const unsigned long long *mask,

@@ -379,10 +379,12 @@ uint32_t ngd_reduce_chunk(uint32_t n_rep) { return n_rep <= 1 ? 1 : n_rep <= 4 ?
 
 void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, uint32_t n_ks, const double *d_W,
                          uint32_t w_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         double *d_sum, const ngd_fix_flags *fix, const double *d_thr) {
+                         double *d_sum, const ngd_fix_flags *fix, const double *d_thr, uint32_t chunk) {
   if (!n_tiles || !n_rep) return;
   const ngd_fix_flags f = fix && d_thr ? *fix : ngd_fix_flags{nullptr, nullptr, nullptr, 0};
-  switch (ngd_reduce_chunk(n_rep)) {
+  // chunk: one group of a larger job launched on its own (the caller has offset W, d_sum and d_thr to the group's first
+  // replicate) keeps the job's template -- a replicate's bits do not depend on it, its speed does
+  switch (chunk ? chunk : ngd_reduce_chunk(n_rep)) {
     case 1: reduce_wb<1>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
     case 4: reduce_wb<4>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
     case 16: reduce_wb<16>(st, g, slab, n_ks, d_W, w_stride, n_rep, d_tiles, n_tiles, d_sum, f, d_thr); break;
@@ -392,9 +394,9 @@ void ngd_launch_reduce_w(hipStream_t st, const ngd_geom &g, const double *slab, 
 
 void ngd_launch_reduce_c(hipStream_t st, const ngd_geom &g, const uint32_t *C, uint32_t n_blocks, const uint32_t *d_M,
                          uint32_t m_stride, uint32_t n_rep, const ngd_tile *d_tiles, uint32_t n_tiles,
-                         unsigned long long *d_cnt) {
+                         unsigned long long *d_cnt, uint32_t chunk) {
   if (!n_tiles || !n_rep) return;
-  switch (ngd_reduce_chunk(n_rep)) {
+  switch (chunk ? chunk : ngd_reduce_chunk(n_rep)) {
     case 1: reduce_cb<1>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;
     case 4: reduce_cb<4>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;
     case 16: reduce_cb<16>(st, g, C, n_blocks, d_M, m_stride, n_rep, d_tiles, n_tiles, d_cnt); break;

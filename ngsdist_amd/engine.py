@@ -202,6 +202,30 @@ class Engine:
                                    c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
+    def run_job_dist(self, block_maps=None, block_size=1, evol_model=0, mult=None, out=None, tot_sites=0):
+        """a job and the tail of gen_dist() in one call (ngd_run_job_dist; mult given: ngd_run_mult_batch_dist, no leading
+        full-data matrix): the finished distances, [n_matrices][n_pairs]; the sums and counts stay in the engine
+        (fetch_matrix)"""
+        if mult is not None:
+            a = np.ascontiguousarray(mult, dtype=np.uint32)
+            if a.ndim != 2:
+                raise ValueError("expected [n_rep][n_blocks]")
+            n_rep, n_blocks = a.shape
+            n_mat, fn, ap = n_rep, self._L.ngd_run_mult_batch_dist, a.ctypes.data_as(C.POINTER(C.c_uint32))
+        elif block_maps is None or len(block_maps) == 0:
+            a, ap, n_rep, n_blocks, n_mat, fn = None, None, 0, 0, 1, self._L.ngd_run_job_dist
+        else:
+            a = np.ascontiguousarray(block_maps, dtype=np.uint64)
+            if a.ndim != 2:
+                raise ValueError("expected [n_rep][n_blocks]")
+            n_rep, n_blocks = a.shape
+            n_mat, fn, ap = n_rep + 1, self._L.ngd_run_job_dist, a.ctypes.data_as(C.POINTER(C.c_uint64))
+        d = np.empty((n_mat, self.n_pairs), dtype=np.float64) if out is None else out
+        if d.shape != (n_mat, self.n_pairs) or d.dtype != np.float64 or not d.flags.c_contiguous:
+            raise ValueError("out: expected a C-contiguous float64 array [n_matrices][n_pairs]")
+        _check(fn(self._h, ap, n_rep, n_blocks, int(block_size), int(tot_sites), int(evol_model), d.ctypes.data_as(C.POINTER(C.c_double))))
+        return d
+
     def run_job_keep(self, block_maps, block_size=1):
         """ngd_run_job with the matrices left in the engine; fetch_matrix(r) copies them out one at a time"""
         a = np.ascontiguousarray(block_maps, dtype=np.uint64)

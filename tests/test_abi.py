@@ -44,7 +44,7 @@ def test_signatures_are_plain_c():
 
 def test_abi_version_and_struct_sizes(lib):
     from ngsdist_amd import _lib
-    assert lib.ngd_abi_version() == 5  # 5: ngd_finish_stream, the staging ring's options (4: ngd_last_spill_timing (3: ngd_config.single_image / second_image_mib in the former reserved words; 2: named launch-geometry fields))
+    assert lib.ngd_abi_version() == 6  # 6: ngd_run_job_dist / ngd_run_mult_batch_dist (5: ngd_finish_stream, the staging ring's options; 4: ngd_last_spill_timing (3: ngd_config.single_image / second_image_mib in the former reserved words; 2: named launch-geometry fields))
     assert C.sizeof(_lib.NgdConfig) == 8 + 8 + 72 + 4 * 4 + 2 * 4 + 6 * 4
     assert C.sizeof(_lib.NgdTiming) == 4 * 8 + 2 * 8
     assert C.sizeof(_lib.NgdSpillTiming) == 4 * 8 + 9 * 8

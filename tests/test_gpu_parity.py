@@ -389,6 +389,100 @@ def test_matrices_of_a_job_fetched_one_at_a_time(kernel):
             e.fetch_matrix(0)
 
 
+def same_bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+@pytest.mark.parametrize("kernel,block_size,pdel,partials,spill", [
+    ("mfma", 8, True, True, 1), ("mfma", 8, False, True, 1), ("mfma", 7, False, True, 1), ("mfma", 1, True, False, 1),
+    ("stream", 3, False, True, 1), ("em_fast", 5, True, True, 1), ("em_faithful", 3, False, False, 1),
+    ("em_table", 5, True, True, 1), ("em_table", 1, False, False, 1), ("em_table", 7, True, False, 0)])
+@pytest.mark.parametrize("n_rep", [0, 1, 5, 33, 70])
+@pytest.mark.parametrize("evol_model", [0, 2])
+def test_job_and_the_tail_of_gen_dist_in_one_call(kernel, block_size, pdel, partials, spill, n_rep, evol_model):
+    """ngd_run_job_dist / ngd_run_mult_batch_dist: the job's matrices leave the device in chunks while -- per-block partials --
+    the later groups of 32 replicates are still being reduced, and the host finishes each chunk as it lands: the same BITS
+    as ngd_run_job followed by ngd_finish on every matrix (ngsDist.cpp:372-401), whatever plan the engine picks, with
+    missing data (nan and inf cells among them when a pair has no valid site); the sums and counts stay in the engine."""
+    n_ind, n_sites = 23, 903
+    indep = kernel in INDEP_KERNELS
+    p = O.synth_indmajor(32, n_ind, n_sites, miss_frac=0.25)
+    p[3] = p[4] = 1.0 / 3  # missing everywhere (--pairwise_del: pairs without a single valid site -> 0 / 0)
+    rng = N().Taus(6)
+    n_eff = n_sites - n_sites % block_size
+    maps = np.stack([rng.block_map(n_eff // block_size) for _ in range(n_rep)]) if n_rep else None
+    with N().Engine(n_ind, n_sites, pairwise_del=pdel, indep_geno=indep, kernel=kernel) as e:
+        e.set_option("boot_partials", 1 if partials else 0).set_option("em_spill", spill)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, block_size)
+        with np.errstate(all="ignore"):
+            want = N().finish(S.reshape(-1), Cn.reshape(-1), 0, evol_model).reshape(S.shape)
+        for again in range(2):  # (the second call: pinned memory, events and the copy stream are the first call's)
+            D = e.run_job_dist(maps, block_size, evol_model)
+            assert D.shape == want.shape and same_bits(D, want)
+        for r in sorted({0, n_rep}):
+            s, c = e.fetch_matrix(r)
+            assert same_bits(s, S[r]) and np.array_equal(c, Cn[r])
+        if n_rep:  # multiplicities, no leading matrix
+            mult = np.stack([np.bincount(m.astype(np.int64), minlength=n_eff // block_size) for m in maps]).astype(np.uint32)
+            mult[0] = 0  # a matrix that visits no site: 0 / 0 in every cell
+            S2, C2 = e.run_batch(mult=mult, block_size=block_size)
+            with np.errstate(all="ignore"):
+                want2 = N().finish(S2.reshape(-1), C2.reshape(-1), 0, evol_model).reshape(S2.shape)
+            D2 = e.run_job_dist(block_size=block_size, evol_model=evol_model, mult=mult)
+            assert same_bits(D2, want2) and np.all(np.isnan(D2[0]))
+        with pytest.raises(N().engine.NgdError):
+            e.run_job_dist(maps, block_size, 3)  # (the reference: "model not yet supported")
+        if pdel:  # parse_args.cpp:209-210
+            with pytest.raises(N().engine.NgdError):
+                e.run_job_dist(maps, block_size, evol_model, tot_sites=1000)
+        else:  # --tot_sites: the count of every cell (ngsDist.cpp:372-373)
+            with np.errstate(all="ignore"):
+                want_t = N().finish(S.reshape(-1), Cn.reshape(-1), 1000, evol_model).reshape(S.shape)
+            assert same_bits(e.run_job_dist(maps, block_size, evol_model, tot_sites=1000), want_t)
+        assert same_bits(e.run_job_dist(maps, block_size, evol_model), want)
+
+
+@pytest.mark.parametrize("pairwise_del", [False, True])
+def test_job_in_one_call_when_the_fixup_pass_patches_the_partial_results(pairwise_del):
+    """ngd_run_job_dist on a one-image engine whose data hold nearly identical individuals: the groups' copies are queued
+    before the noted pairs are known; once the fix-up pass has patched the per-block partial results the replicates are
+    reduced again and EVERY matrix leaves the device again -- nothing of the first copies has been declared landed."""
+    n_ind, n_sites, B, n_rep = 400, 4000, 100, 40
+    rng = np.random.default_rng(3)
+    p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.05 if pairwise_del else 0.0)
+    g = rng.integers(0, 3, size=n_sites)
+    for k in (5, 6, 7, 200):
+        q = 1e-12 * (1 + rng.random((n_sites, 3)))
+        q[np.arange(n_sites), g] = 0
+        q[np.arange(n_sites), g] = 1 - q.sum(axis=1)
+        p[k] = q
+    maps = np.stack([N().Taus(r + 1).block_map(n_sites // B) for r in range(n_rep)])
+    with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, kernel="mfma", single_image=2) as e:
+        e.set_option("boot_partials", 2)
+        e.upload_ind_major(p).commit()
+        S, Cn = e.run_job(maps, B)
+        assert e.fixup()["recomputed"] >= 6
+        want = N().finish(S.reshape(-1), Cn.reshape(-1), 0, 1).reshape(S.shape)
+        D = e.run_job_dist(maps, B, 1)
+        f = e.fixup()
+        assert f["recomputed"] >= 6 and f["skipped"] == 0
+        assert same_bits(D, want)
+    sub = np.array([5, 6, 7, 200, 11])
+    so, co = O.all_pairs(np.ascontiguousarray(p[sub]), pairwise_del=pairwise_del, n_threads=8)
+    idx = [N()._lib.load().ngd_pair_index(n_ind, int(min(a, b)), int(max(a, b))) for k, a in enumerate(sub) for b in sub[k + 1:]]
+    assert np.array_equal(Cn[0][idx], co) and rel_err(S[0][idx], so) < RTOL
+
+
+def test_job_in_one_call_wants_whole_matrices():
+    """an engine that owns a share of the pairs holds part of every matrix: the tail cannot be applied to it"""
+    p = O.synth_indmajor(1, 140, 64)
+    with N().Engine(140, 64, kernel="mfma", shard_rank=0, shard_world=2) as e:
+        e.upload_ind_major(p).commit()
+        with pytest.raises(N().engine.NgdError):
+            e.run_job_dist()
+
+
 @pytest.mark.parametrize("kernel", ["em_table", "em_fast", "em_faithful"])
 def test_em_batch_pass_that_does_not_fit_falls_back_to_one_pass_per_matrix(kernel):
     """the EM batch pass needs RB result planes per slice; when they exceed the scratch budget (NGD_OPT_BOOT_MAX_BYTES,

@@ -6,6 +6,8 @@
 #             and the host-side pipelines side by side (tools/host_read_pipeline)
 #   counters: tools/profile.sh per workload (kernel trace reconciled against an unprofiled line of the same lease)
 #   lines:    the bench lines committed under profiles/r06_bench_lines/
+#   tail:     bootstrap jobs through ngd_run_mult_batch_dist (the job and its tail in one call) against the round-5 form of the
+#             tail (--split_tail), interleaved in one lease, then the bootstrap workloads' lines again
 # Everything lands under gpurun_out/; what is judged is copied to profiles/ by hand.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -43,4 +45,25 @@ if [ "$PART" = lines ]; then
   line emboot_block1 --workload emboot --block 1 --no_cpu
   line cfg3_two_images --workload cfg3 --single_image 3 --no_cpu
   python3 tools/ab_lines.py "$OUT"/cfg*.json "$OUT"/emboot*.json
+fi
+if [ "$PART" = tail ]; then
+  for i in 1 2 3; do
+    line tail_cfg5_one_$i --workload cfg5 --no_cpu --serial_tail
+    line tail_cfg5_split_$i --workload cfg5 --no_cpu --serial_tail --split_tail
+  done
+  for i in 1 2; do
+    line tail_emboot_one_$i --workload emboot --no_cpu --serial_tail
+    line tail_emboot_split_$i --workload emboot --no_cpu --serial_tail --split_tail
+  done
+  python3 - "$OUT" <<'PY'
+import glob, json, sys
+for f in sorted(glob.glob(sys.argv[1] + "/tail_*.json")):
+    j = json.loads(open(f).read())
+    print("%s: step %.3f ms, dominant kernel %.3f ms, valid %s" % (f.split("/")[-1], j["ms_per_step"], j["roofline"]["ms_per_launch"], j["valid"]))
+PY
+  line cfg5 --workload cfg5 --steps 10 --warmup 3
+  line emboot --workload emboot
+  line emboot_5_replicates --workload emboot --n_boot 5 --no_cpu
+  line emboot_block1 --workload emboot --block 1 --no_cpu
+  python3 tools/ab_lines.py "$OUT"/cfg5.json "$OUT"/emboot*.json
 fi
