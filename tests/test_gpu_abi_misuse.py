@@ -54,6 +54,7 @@ def test_bad_arguments_are_codes_and_the_engine_survives():
     c = np.zeros(4 * n_pairs, dtype=np.uint64)
     sp, cp = s.ctypes.data_as(dp), c.ctypes.data_as(u64p)
     err(L.ngd_run(h, None, 0, 0, sp, cp))  # nothing uploaded / committed
+    err(L.ngd_run_job_dist(h, None, 0, 0, 0, 0, 1, sp))
     err(L.ngd_commit(None))
     p = O.synth_indmajor(1, n_ind, n_sites)
     err(L.ngd_upload_ind_major(h, None))
@@ -80,6 +81,15 @@ def test_bad_arguments_are_codes_and_the_engine_survives():
     err(L.ngd_run_mult(h, mult.ctypes.data_as(u32p), 5, 10, sp, cp))
     err(L.ngd_run_mult_batch(h, None, 1, 4, 10, sp, cp))
     err(L.ngd_run_mult_batch(h, mult.ctypes.data_as(u32p), 0, 4, 10, sp, cp))
+    err(L.ngd_run_job_dist(h, mp, 1, 4, 10, 0, 1, None))       # no output
+    err(L.ngd_run_job_dist(h, None, 2, 4, 10, 0, 1, sp))        # replicates without block maps
+    err(L.ngd_run_job_dist(h, mp, 1, 4, 10, 0, 5, sp))          # evolutionary model 5: "not yet supported"
+    err(L.ngd_run_job_dist(h, mp, 1, 4, 11, 0, 1, sp))          # 44 sites > 40
+    err(L.ngd_run_job_dist(h, badmap.ctypes.data_as(u64p), 1, 4, 10, 0, 1, sp))
+    err(L.ngd_run_job_dist(None, mp, 1, 4, 10, 0, 1, sp))
+    err(L.ngd_run_mult_batch_dist(h, None, 1, 4, 10, 0, 1, sp))
+    err(L.ngd_run_mult_batch_dist(h, mult.ctypes.data_as(u32p), 0, 4, 10, 0, 1, sp))
+    assert L.ngd_run_job_dist(h, mp, 1, 4, 10, 0, 1, sp) == 0   # (and a good one after the bad ones)
     err(L.ngd_run_device(h, None, 0, 0, None, None))
     err(L.ngd_run_job_device(h, mp, 1, 4, 10, None, None))
     err(L.ngd_set_option(h, 9999, 1))
@@ -140,6 +150,7 @@ def test_engines_give_their_device_memory_back():
             e.upload_ind_major(p).commit()
             e.run()
             e.run_job(maps, B)
+            e.run_job_dist(maps if it % 5 else maps[:1 + it % 3], B, it % 3)  # (pinned buffers, events and copy streams of the engine's)
             e.run(maps[0], B)
         with pytest.raises(N.NgdError):
             N.Engine(n_ind, 1 << 40)  # far too large: the pieces allocated before the failure are freed again
@@ -178,6 +189,12 @@ def test_nothing_to_fetch_after_a_failed_job():
         for which in (0, 3):
             with pytest.raises(N.NgdError):
                 e.fetch_matrix(which)
+        e.run_job_dist(maps, B, 1)
+        e.fetch_matrix(3)
+        with pytest.raises(N.NgdError):
+            e.run_job_dist(bad, B, 1)  # (the one-call job: the same rule)
+        with pytest.raises(N.NgdError):
+            e.fetch_matrix(0)
         assert e.run_job_keep(maps, B) == 4  # and the engine goes on
         s, c = e.fetch_matrix(1)
         s1, c1 = e.run(maps[0], B)
