@@ -20,7 +20,10 @@
  *  - calls on one engine are not thread-safe (one caller, like main()).
  *  - pair order is the reference's: row-major upper triangle, i1 < i2
  *    (ngsDist.cpp:244-245); n_pairs = n_ind*(n_ind-1)/2.
- *  - results are deterministic run to run (no floating-point atomics).
+ *  - results are deterministic run to run (no floating-point atomics): the same calls in the same order on a new engine
+ *    give the same bits.  Two calls of the same bootstrap job on ONE engine may take different plans (NGD_OPT_BOOT_PARTIALS
+ *    = 1 serves the first calls of a geometry without the per-block partial results while their slab would cost more to
+ *    allocate than it has saved) and then agree to rounding, not bit for bit; 0 or 2 pin the plan.
  *  - there is no CPU fallback: without a HIP device ngd_create() fails.
  */
 #ifndef NGSDIST_AMD_H

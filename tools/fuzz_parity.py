@@ -132,6 +132,17 @@ for case in range(first, first + n_cases):
             else:
                 e.upload_ind_major(p).commit()
             S, Cn = e.run_job(maps, B)
+            # (round 6) a third of the one-engine cases also take the job and its tail in ONE call (ngd_run_job_dist: groups of
+            # replicates copied out beside the later groups' reductions, the host finishing chunks as they land): the same bits
+            # as ngd_run_job + ngd_finish on every matrix
+            if rng_r6.integers(0, 3) == 0:
+                with np.errstate(all="ignore"):
+                    want = N.finish(S.reshape(-1), Cn.reshape(-1), 0, model).reshape(S.shape)
+                    got = e.run_job_dist(maps, B, model)
+                if not np.array_equal(got.view(np.uint64), want.view(np.uint64)):
+                    bad += 1
+                    print("MISMATCH", tag, "ngd_run_job_dist against ngd_run_job + ngd_finish", flush=True)
+                tag = tag + ("one_call",)
         for m in sorted({0, n_rep // 2, n_rep}):
             src = None if m == 0 else O.boot_site_src(maps[m - 1], B)
             if m and big:
