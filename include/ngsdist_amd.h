@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NGD_ABI_VERSION 6 /* 6: ngd_run_job_dist, ngd_run_mult_batch_dist; 5: ngd_finish_stream, ngd_fixup_info.by_pass, NGD_OPT_STAGE_PIECE_MIB / _STAGE_RING / _EAGER_FULL, NGD_OPT_FIXUP_WORK 0 = no budget (every noted pair is recomputed); 4: ngd_last_spill_timing, ngd_last_fixup, ngd_image_mode, ngd_config.single_image 0 = auto / 3 = two images; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
+#define NGD_ABI_VERSION 6 /* 6: ngd_run_job_dist, ngd_run_batch_dist, ngd_run_mult_batch_dist; 5: ngd_finish_stream, ngd_fixup_info.by_pass, NGD_OPT_STAGE_PIECE_MIB / _STAGE_RING / _EAGER_FULL, NGD_OPT_FIXUP_WORK 0 = no budget (every noted pair is recomputed); 4: ngd_last_spill_timing, ngd_last_fixup, ngd_image_mode, ngd_config.single_image 0 = auto / 3 = two images; 3: ngd_config.single_image / second_image_mib (were reserved, zero), ngd_fetch_matrix, ngd_score_congruence */
 
 #define NGD_OK 0
 #define NGD_E_INVALID (-1)  /* bad argument / bad state                    */
@@ -275,8 +275,9 @@ int ngd_run_job_device(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep
  * engine's next run call. */
 int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt);
 /* A job AND the tail of gen_dist() (ngsDist.cpp:217-289 with :372-401) in one call: `dist` ([n_rep + 1][n_pairs] for
- * ngd_run_job_dist -- [1][n_pairs] when n_rep = 0 --, [n_rep][n_pairs] for ngd_run_mult_batch_dist; any host memory)
- * receives what ngd_run_job() / ngd_run_mult_batch() followed by ngd_finish() on every matrix would give, bit for bit.
+ * ngd_run_job_dist -- [1][n_pairs] when n_rep = 0 --, [n_rep][n_pairs] for ngd_run_batch_dist / ngd_run_mult_batch_dist; any host memory)
+ * receives what ngd_run_job() / ngd_run_batch() / ngd_run_mult_batch() followed by ngd_finish() on every matrix would give, bit
+ * for bit.
  * The sums (and, --pairwise_del, the counts) leave the device in chunks of about 8 MiB on a stream of the engine's own into
  * pinned memory the engine keeps, and up to 64 host threads turn each chunk into distances as it lands; in the
  * per-block-partials plan a group of 32 replicates is reduced by a launch of its own and its copy follows at once, beside
@@ -286,6 +287,8 @@ int ngd_fetch_matrix(ngd_engine *e, uint32_t which, double *sum, uint64_t *cnt);
  * NGD_E_INVALID on an engine that owns a share of the pairs (ngd_config.shard_world > 1: its matrices are partial). */
 int ngd_run_job_dist(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
                      uint64_t tot_sites, uint64_t evol_model, double *dist);
+int ngd_run_batch_dist(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                       uint64_t tot_sites, uint64_t evol_model, double *dist); /* replicates only, as ngd_run_batch */
 int ngd_run_mult_batch_dist(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
                             uint64_t tot_sites, uint64_t evol_model, double *dist);
 

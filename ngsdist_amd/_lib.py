@@ -66,7 +66,7 @@ EXPORTS = [
     "ngd_upload_sites", "ngd_upload_ind_major", "ngd_commit", "ngd_stage_acquire", "ngd_stage_submit",
     "ngd_upload_raw_sites", "ngd_synth_fill", "ngd_synth_fill_range", "ngd_run", "ngd_run_mult", "ngd_run_mult_device",
     "ngd_run_device", "ngd_run_batch", "ngd_run_batch_device", "ngd_run_mult_batch",
-    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_run_job_dist", "ngd_run_mult_batch_dist", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_fixup", "ngd_image_mode", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_finish_stream", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
+    "ngd_run_mult_batch_device", "ngd_run_job", "ngd_run_job_device", "ngd_run_job_dist", "ngd_run_batch_dist", "ngd_run_mult_batch_dist", "ngd_fetch_matrix", "ngd_drop_caches", "ngd_set_option", "ngd_last_timing", "ngd_last_spill_timing", "ngd_last_fixup", "ngd_image_mode", "ngd_last_shader_clock", "ngd_last_em_work", "ngd_finish", "ngd_finish_stream", "ngd_format_matrix", "ngd_taus_seed", "ngd_taus_get",
     "ngd_taus_uniform", "ngd_boot_block_map", "ngd_n_pairs", "ngd_pair_index", "ngd_device_bytes", "ngd_device_memory", "ngd_shard_of_pair", "ngd_shard_map",
     "ngd_score_congruence",
 ]
@@ -121,6 +121,7 @@ def load():
     L.ngd_run_job_device.argtypes = [vp, u64p, C.c_uint32, u64, u64, vp, vp]
     L.ngd_fetch_matrix.argtypes = [vp, C.c_uint32, dp, u64p]
     L.ngd_run_job_dist.argtypes = [vp, u64p, C.c_uint32, u64, u64, u64, u64, dp]
+    L.ngd_run_batch_dist.argtypes = [vp, u64p, C.c_uint32, u64, u64, u64, u64, dp]
     L.ngd_run_mult_batch_dist.argtypes = [vp, u32p, C.c_uint32, u64, u64, u64, u64, dp]
     L.ngd_run_mult_batch_device.argtypes = [vp, u32p, C.c_uint32, u64, u64, vp, vp]
     L.ngd_drop_caches.argtypes = [vp]

@@ -2619,6 +2619,12 @@ int ngd_run_job_dist(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, 
   return run_dist(e, block_maps, nullptr, n_rep, true, n_blocks, block_size, tot_sites, evol_model, dist, "ngd_run_job_dist");
 }
 
+int ngd_run_batch_dist(ngd_engine *e, const uint64_t *block_maps, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
+                       uint64_t tot_sites, uint64_t evol_model, double *dist) {
+  if (!block_maps || !n_rep) return fail(NGD_E_INVALID, "ngd_run_batch_dist: null argument");
+  return run_dist(e, block_maps, nullptr, n_rep, false, n_blocks, block_size, tot_sites, evol_model, dist, "ngd_run_batch_dist");
+}
+
 int ngd_run_mult_batch_dist(ngd_engine *e, const uint32_t *mult, uint32_t n_rep, uint64_t n_blocks, uint64_t block_size,
                             uint64_t tot_sites, uint64_t evol_model, double *dist) {
   if (!mult || !n_rep) return fail(NGD_E_INVALID, "ngd_run_mult_batch_dist: null argument");

@@ -202,9 +202,9 @@ class Engine:
                                    c.ctypes.data_as(C.POINTER(C.c_uint64))))
         return s, c
 
-    def run_job_dist(self, block_maps=None, block_size=1, evol_model=0, mult=None, out=None, tot_sites=0):
-        """a job and the tail of gen_dist() in one call (ngd_run_job_dist; mult given: ngd_run_mult_batch_dist, no leading
-        full-data matrix): the finished distances, [n_matrices][n_pairs]; the sums and counts stay in the engine
+    def run_job_dist(self, block_maps=None, block_size=1, evol_model=0, mult=None, out=None, tot_sites=0, lead_full=True):
+        """a job and the tail of gen_dist() in one call (ngd_run_job_dist; lead_full=False: ngd_run_batch_dist, mult given:
+        ngd_run_mult_batch_dist -- no leading full-data matrix): the finished distances, [n_matrices][n_pairs]; the sums and counts stay in the engine
         (fetch_matrix)"""
         if mult is not None:
             a = np.ascontiguousarray(mult, dtype=np.uint32)
@@ -220,6 +220,8 @@ class Engine:
                 raise ValueError("expected [n_rep][n_blocks]")
             n_rep, n_blocks = a.shape
             n_mat, fn, ap = n_rep + 1, self._L.ngd_run_job_dist, a.ctypes.data_as(C.POINTER(C.c_uint64))
+            if not lead_full:  # replicates only (ngd_run_batch_dist)
+                n_mat, fn = n_rep, self._L.ngd_run_batch_dist
         d = np.empty((n_mat, self.n_pairs), dtype=np.float64) if out is None else out
         if d.shape != (n_mat, self.n_pairs) or d.dtype != np.float64 or not d.flags.c_contiguous:
             raise ValueError("out: expected a C-contiguous float64 array [n_matrices][n_pairs]")

@@ -431,6 +431,10 @@ def test_job_and_the_tail_of_gen_dist_in_one_call(kernel, block_size, pdel, part
                 want2 = N().finish(S2.reshape(-1), C2.reshape(-1), 0, evol_model).reshape(S2.shape)
             D2 = e.run_job_dist(block_size=block_size, evol_model=evol_model, mult=mult)
             assert same_bits(D2, want2) and np.all(np.isnan(D2[0]))
+            S3, C3 = e.run_batch(maps, block_size)  # and block maps without the leading matrix (ngd_run_batch_dist)
+            with np.errstate(all="ignore"):
+                want3 = N().finish(S3.reshape(-1), C3.reshape(-1), 0, evol_model).reshape(S3.shape)
+            assert same_bits(e.run_job_dist(maps, block_size, evol_model, lead_full=False), want3)
         with pytest.raises(N().engine.NgdError):
             e.run_job_dist(maps, block_size, 3)  # (the reference: "model not yet supported")
         if pdel:  # parse_args.cpp:209-210
