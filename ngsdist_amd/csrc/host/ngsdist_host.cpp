@@ -1194,7 +1194,9 @@ int main(int argc, char **argv) {
 
   // one matrix of the output: the reference's progress lines in its order (:218-241, :281), the tail of gen_dist
   // and the print block
-  auto emit = [&](uint64_t rep, const double *rs, const uint64_t *rc_, const uint64_t *bm, uint64_t n_blocks) {
+  auto emit = [&](uint64_t rep, const double *rs, const uint64_t *rc_, const uint64_t *bm, uint64_t n_blocks,
+                  const double *ready = nullptr /* the matrix's distances, finished already (beside the matrix before it) */,
+                  int ready_rc = 0) {
     if (p.verbose >= 1) {
       if (rep == 0) fprintf(stderr, "==> Analyzing full dataset...\n");
       else fprintf(stderr, "==> Bootstrap replicate # %lu ...\n", rep);
@@ -1214,20 +1216,26 @@ int main(int argc, char **argv) {
           fprintf(stderr, "\tDistance of %f from %lu valid sites (%f) between %s (ind %lu) and %s (ind %lu)!\n",
                   rs[k], rc_[k], rs[k] / (double)rc_[k], labels[i1].c_str(), i1, labels[i2].c_str(), i2);
     }
-    const auto t_f0 = std::chrono::steady_clock::now();
-    int rc = ngd_finish(rs, rc_, n_comb, p.tot_sites, p.evol_model, dist.data());
-    if (rc) die("gen_dist", "invalid evolutionary model specified!");
-    t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
+    const double *cells = ready;
+    if (ready) {
+      if (ready_rc) die("gen_dist", "invalid evolutionary model specified!");
+    } else {
+      const auto t_f0 = std::chrono::steady_clock::now();
+      int rc = ngd_finish(rs, rc_, n_comb, p.tot_sites, p.evol_model, dist.data());
+      if (rc) die("gen_dist", "invalid evolutionary model specified!");
+      t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
+      cells = dist.data();
+    }
 
     if (p.verbose >= 2) fprintf(stderr, "> Printing distance matrix\n");
     // ngsDist.cpp:282-287 (join(), gen_func.cpp:479-496); rows formatted in parallel, same bytes
     const auto t_w0 = std::chrono::steady_clock::now();
     std::vector<char> &text = text_buf[n_emitted++ & 1];  // (the writer may still be on the other one)
     if (text.empty()) text.resize(64 + p.n_ind * (p.n_ind * 16 + 64));
-    int64_t need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+    int64_t need = ngd_format_matrix(cells, p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
     if (need > (int64_t)text.size()) {
       text.resize((size_t)need);
-      need = ngd_format_matrix(dist.data(), p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
+      need = ngd_format_matrix(cells, p.n_ind, label_ptr.data(), text.data(), text.size(), p.n_threads);
     }
     if (need < 0) die(__FUNCTION__, "cannot format the distance matrix");
     writer.wait_idle();  // the previous matrix is on its way out: matrices are written in order, one at a time
@@ -1452,15 +1460,39 @@ int main(int argc, char **argv) {
     }
     run_all(block_maps.data(), (uint32_t)n_boot_here, with_full, n_blocks);
     t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
-    for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
-      if (in_engine) {
+    if (in_engine) {
+      // a batch's matrices come out of the engine one at a time -- and matrix r + 1 is fetched and finished (ngd_fetch_matrix,
+      // ngd_finish) by a thread of its own while matrix r is formatted and handed to the writer: two sets of buffers
+      struct Pre {
+        std::vector<double> sum, dist;
+        std::vector<uint64_t> cnt;
+        int rc_fetch = 0, rc_finish = 0;
+        std::string err;
+        std::thread th;
+      } pre[2];
+      auto start = [&](uint64_t r) {
+        Pre &q = pre[r & 1];
+        q.sum.resize(n_comb); q.dist.resize(n_comb); q.cnt.resize(n_comb);
+        q.th = std::thread([&q, r, &eng, &p, n_comb]() {
+          q.rc_fetch = ngd_fetch_matrix(eng.h, (uint32_t)r, q.sum.data(), q.cnt.data());
+          if (q.rc_fetch) { q.err = ngd_last_error(); return; }  // (the message is the fetching thread's)
+          q.rc_finish = ngd_finish(q.sum.data(), q.cnt.data(), n_comb, p.tot_sites, p.evol_model, q.dist.data());
+        });
+      };
+      start(0);
+      for (uint64_t r = 0; r < n_in_batch; r++, rep++) {
+        Pre &q = pre[r & 1];
         const auto t_g0 = std::chrono::steady_clock::now();
-        int rc = ngd_fetch_matrix(eng.h, (uint32_t)r, sum.data(), cnt.data());
-        if (rc) die_engine("ngd_fetch_matrix", rc);
+        q.th.join();
         t_compute += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_g0).count();
+        if (q.rc_fetch) die("ngd_fetch_matrix", (std::string("engine error ") + std::to_string(q.rc_fetch) + ": " + q.err).c_str());
+        if (r + 1 < n_in_batch) start(r + 1);
+        emit(rep, q.sum.data(), q.cnt.data(), rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks,
+             q.dist.data(), q.rc_finish);
       }
-      emit(rep, in_engine ? sum.data() : &sum[r * n_comb], in_engine ? cnt.data() : &cnt[r * n_comb],
-           rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks);
+    } else {
+      for (uint64_t r = 0; r < n_in_batch; r++, rep++)
+        emit(rep, &sum[r * n_comb], &cnt[r * n_comb], rep > 0 ? &block_maps[(r - (with_full ? 1 : 0)) * n_blocks] : nullptr, n_blocks);
     }
   }
   g_phases.mark("matrices");

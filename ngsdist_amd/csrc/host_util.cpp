@@ -210,75 +210,148 @@ int64_t ngd_format_matrix(const double *dist, uint64_t n_ind, const char *const 
   // shares of rows, finer than the threads (rows near the top hold more upper-triangle cells: dist is read row-wise there,
   // column-wise below the diagonal); every share formats into a buffer of its own, sized by the longest a cell can be
   const unsigned n_parts = nt == 1 ? 1 : (unsigned)std::min<uint64_t>(n_ind, 4ull * nt);
-  struct Part { std::vector<char> buf; size_t len = 0; };
-  std::vector<Part> part(n_parts);
+  // The shares' buffers are the calling thread's and are kept from call to call (a job prints a hundred matrices of 13 MB: a
+  // fresh vector per share and call is an mmap, its zero fill and its page faults every time)
+  struct Scratch {
+    std::vector<char *> buf;
+    std::vector<size_t> cap;
+    ~Scratch() { for (char *b : buf) free(b); }
+    bool reserve(unsigned t, size_t need) {  // (keeps the contents: a share may grow while it is being written)
+      if (t < cap.size() && cap[t] >= need) return true;
+      if (t >= buf.size()) return false;
+      char *nb = (char *)realloc(buf[t], need);
+      if (!nb) return false;
+      buf[t] = nb;
+      cap[t] = need;
+      return true;
+    }
+  };
+  static thread_local Scratch scratch_tl;
+  Scratch &scratch = scratch_tl;  // (the pool's threads must see the CALLER's buffers, not thread-local ones of their own)
+  if (scratch.buf.size() < n_parts) { scratch.buf.resize(n_parts, nullptr); scratch.cap.resize(n_parts, 0); }
+  std::vector<size_t> part_len(n_parts, 0);
+  std::atomic<bool> oom{false};
   std::vector<size_t> label_len(n_ind);
   for (uint64_t i = 0; i < n_ind; i++) label_len[i] = strlen(labels[i]);
+  // (more threads asked for than the pool of 16 holds: the wide pool's 64 -- [measured, round 6] threads of the call's own,
+  // made and joined per matrix, took three times as long as 16 pooled ones)
+  const bool wide = n_threads > 16;
+  auto run_parts = [&](const std::function<void(unsigned)> &fn) {
+    if (nt == 1) {
+      for (unsigned t = 0; t < n_parts; t++) fn(t);
+    } else {
+      (wide ? host_pool_wide() : host_pool()).run(n_parts, fn);
+    }
+  };
+  char head[32];
+  const int hn = snprintf(head, sizeof(head), "\n%lu\n", (unsigned long)n_ind);
+
+  // The regular matrix -- every cell prints as "d.dddddddddd", 12 bytes: what distances are -- is formatted ONCE per pair
+  // (the printed matrix is symmetric: the general form below formats every cell twice and walks a column of the upper
+  // triangle for the cells under the diagonal) into 12-byte slots in pair order; the rows, all of one known length, are
+  // then put together from the slots straight into `out`.  Any other cell (a sign, nan, inf, 10 and above) anywhere: the
+  // general form.
+  if (out && nt > 1) {
+    uint64_t total_fixed = (uint64_t)hn;
+    std::vector<uint64_t> row_at(n_ind);
+    for (uint64_t i = 0; i < n_ind; i++) { row_at[i] = total_fixed; total_fixed += label_len[i] + n_ind * 13 + 1; }
+    const uint64_t n_pairs = n_ind * (n_ind - 1) / 2;
+    struct Slots { char *p = nullptr; size_t cap = 0; ~Slots() { free(p); } };
+    static thread_local Slots slots_tl;
+    Slots &slots = slots_tl;
+    if (cap >= total_fixed && (slots.cap >= n_pairs * 12 || [&] {
+          char *np_ = (char *)realloc(slots.p, n_pairs * 12);
+          if (np_) { slots.p = np_; slots.cap = n_pairs * 12; }
+          return np_ != nullptr;
+        }())) {
+      std::atomic<bool> irregular{false};
+      char *const sl = slots.p;
+      run_parts([&](unsigned t) {
+        const uint64_t lo = n_pairs * t / n_parts, hi = n_pairs * (t + 1) / n_parts;
+        char tmp[448];
+        for (uint64_t k = lo; k < hi; k++) {
+          const char *e = fmt_fixed10(dist[k], tmp);
+          if (e - tmp != 12) { irregular.store(true, std::memory_order_relaxed); return; }
+          memcpy(sl + 12 * k, tmp, 12);
+        }
+      });
+      if (!irregular.load()) {
+        memcpy(out, head, (size_t)hn);
+        run_parts([&](unsigned t) {
+          const uint64_t lo = n_ind * t / n_parts, hi = n_ind * (t + 1) / n_parts;
+          for (uint64_t i = lo; i < hi; i++) {
+            char *o = out + row_at[i];
+            memcpy(o, labels[i], label_len[i]);
+            o += label_len[i];
+            uint64_t k = i - 1;  // cell (j, i), j < i: pair index j (2n - j - 1) / 2 + (i - j - 1), its step from j to j + 1 is n - j - 2
+            for (uint64_t j = 0; j < i; j++) {
+              *o++ = '\t';
+              memcpy(o, sl + 12 * k, 12);
+              o += 12;
+              k += n_ind - j - 2;
+            }
+            memcpy(o, "\t0.0000000000", 13);
+            o += 13;
+            const char *row = sl + 12 * (i * (2 * n_ind - i - 1) / 2);  // the slots of cells (i, j), j > i, side by side
+            for (uint64_t j = i + 1; j < n_ind; j++, row += 12) {
+              *o++ = '\t';
+              memcpy(o, row, 12);
+              o += 12;
+            }
+            *o = '\n';
+          }
+        });
+        return (int64_t)total_fixed;
+      }
+    }
+  }
   auto rows = [&](unsigned t) {
     const uint64_t lo = n_ind * t / n_parts, hi = n_ind * (t + 1) / n_parts;
     size_t need = 0;
     for (uint64_t i = lo; i < hi; i++) need += label_len[i] + n_ind * 24 + 1;  // ("\t" + sign + 9 digits + "." + 10 = 22 at most below 2^29)
-    Part &P = part[t];
-    P.buf.resize(need + 512);
-    char *o = P.buf.data(), *lim = o + P.buf.size() - 450;  // (a cell snprintf may write -- 2^29 and above, 1e300 -- needs up to ~330)
+    if (!scratch.reserve(t, need + 512)) { oom = true; return; }
+    char *o = scratch.buf[t], *lim = o + scratch.cap[t] - 450;  // (a cell snprintf may write -- 2^29 and above, 1e300 -- needs up to ~330)
+    auto grow = [&]() {  // huge cells (never for distances)
+      const size_t used = (size_t)(o - scratch.buf[t]);
+      if (!scratch.reserve(t, scratch.cap[t] * 2 + 1024)) { oom = true; return false; }
+      o = scratch.buf[t] + used;
+      lim = scratch.buf[t] + scratch.cap[t] - 450;
+      return true;
+    };
     for (uint64_t i = lo; i < hi; i++) {
+      if (o + label_len[i] > lim && !grow()) return;
       memcpy(o, labels[i], label_len[i]);
       o += label_len[i];
       // dist_matrix is symmetric with a zero diagonal (gen_dist_slave :411, init_ptr :200): cells (j, i), j < i, walk down
       // a column of the upper triangle -- pair index j (2n - j - 1) / 2 + (i - j - 1), its step from j to j + 1 is n - j - 2
       uint64_t k = i - 1;  // (j = 0)
       for (uint64_t j = 0; j < i; j++) {
-        if (o > lim) {  // huge cells: grow (never for distances)
-          const size_t used = (size_t)(o - P.buf.data());
-          P.buf.resize(P.buf.size() * 2 + 1024);
-          o = P.buf.data() + used;
-          lim = P.buf.data() + P.buf.size() - 450;
-        }
+        if (o > lim && !grow()) return;
         *o++ = '\t';
         o = fmt_fixed10(dist[k], o);
         k += n_ind - j - 2;
       }
-      if (o > lim) { const size_t used = (size_t)(o - P.buf.data()); P.buf.resize(P.buf.size() * 2 + 1024); o = P.buf.data() + used; lim = P.buf.data() + P.buf.size() - 450; }
+      if (o > lim && !grow()) return;
       *o++ = '\t';
       o = fmt_fixed10(0.0, o);
       const double *row = dist + i * (2 * n_ind - i - 1) / 2 - (i + 1);  // row[j] = cell (i, j), j > i
       for (uint64_t j = i + 1; j < n_ind; j++) {
-        if (o > lim) {
-          const size_t used = (size_t)(o - P.buf.data());
-          P.buf.resize(P.buf.size() * 2 + 1024);
-          o = P.buf.data() + used;
-          lim = P.buf.data() + P.buf.size() - 450;
-        }
+        if (o > lim && !grow()) return;
         *o++ = '\t';
         o = fmt_fixed10(row[j], o);
       }
       *o++ = '\n';
     }
-    P.len = (size_t)(o - P.buf.data());
-  };
-  const bool own_threads = n_threads && n_threads > 16;  // more threads asked for than the pool holds: this call's own
-  auto run_parts = [&](const std::function<void(unsigned)> &fn) {
-    if (nt == 1) {
-      for (unsigned t = 0; t < n_parts; t++) fn(t);
-    } else if (own_threads) {
-      std::atomic<unsigned> next{0};
-      std::vector<std::thread> th;
-      for (unsigned w = 0; w < nt; w++)
-        th.emplace_back([&]() { for (unsigned t; (t = next.fetch_add(1)) < n_parts;) fn(t); });
-      for (auto &t : th) t.join();
-    } else {
-      host_pool().run(n_parts, fn);
-    }
+    part_len[t] = (size_t)(o - scratch.buf[t]);
   };
   run_parts(rows);
-  char head[32];
-  const int hn = snprintf(head, sizeof(head), "\n%lu\n", (unsigned long)n_ind);
+  if (oom) return NGD_E_NOMEM;
   uint64_t total = (uint64_t)hn;
   std::vector<uint64_t> at(n_parts);
-  for (unsigned t = 0; t < n_parts; t++) { at[t] = total; total += part[t].len; }
+  for (unsigned t = 0; t < n_parts; t++) { at[t] = total; total += part_len[t]; }
   if (out && cap >= total) {
     memcpy(out, head, (size_t)hn);
-    run_parts([&](unsigned t) { memcpy(out + at[t], part[t].buf.data(), part[t].len); });  // (13 MB for 1000 individuals: in parallel too)
+    run_parts([&](unsigned t) { memcpy(out + at[t], scratch.buf[t], part_len[t]); });  // (13 MB for 1000 individuals: in parallel too)
   }
   return (int64_t)total;
 }

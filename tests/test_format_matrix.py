@@ -49,6 +49,24 @@ def test_format_matrix_matches_printf(n, threads):
     assert got == expected(vals, labels)
 
 
+@pytest.mark.parametrize("n,threads", [(64, 2), (65, 3), (130, 0), (257, 16), (130, 64)])
+@pytest.mark.parametrize("odd_cell", [None, "9.99999999996", "-0.0", "nan", "12.5", "-1e-12"])
+def test_format_matrix_of_ordinary_distances_is_formatted_once_per_pair(n, threads, odd_cell):
+    """every cell "d.dddddddddd": the fast form (a 12-byte slot per pair, the rows put together from the slots) -- the same
+    bytes as printf; ONE other cell anywhere (a value that rounds up to 10.0000000000, a signed zero, nan, 12.5, a negative
+    number) sends the whole matrix through the general form"""
+    rng = np.random.default_rng(n + threads)
+    npair = n * (n - 1) // 2
+    vals = np.concatenate([rng.random(npair // 2) * 9.99, 10.0 ** rng.uniform(-15, 0.99, npair - npair // 2 - 4),
+                           [0.0, 5e-11, 9.9999999999, 0.99999999995]])
+    rng.shuffle(vals)
+    if odd_cell is not None:
+        vals[int(rng.integers(0, npair))] = float(odd_cell)
+    labels = ["Ind_%d" % i if i % 3 else "a longer label %d" % i for i in range(n)]
+    for again in range(2):  # (the buffers are kept from call to call)
+        assert N.format_matrix(vals, labels, n_threads=threads) == expected(vals, labels)
+
+
 def test_format_matrix_many_random_cells():
     rng = np.random.default_rng(0)
     n = 400
