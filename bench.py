@@ -58,7 +58,8 @@ WORKLOADS = {
     # parse_args.cpp:29-31) at cfg 4's shape on 1e5 sites: 101 matrices from ONE pass of the per-site EM -- the terms of
     # every (pair, unit of 10 sites) spilled once, one FP64 MFMA contraction with every matrix's weights (em_spill_impl).
     # Per-block partial results are switched off (10 000 blocks x 8.4 MB = an 84 GB slab, which the engine only buys after
-    # a few jobs have paid its allocation): this is the plan a single job gets.  --n_boot / --block vary the job.
+    # a few jobs have paid its allocation -- since round 6 also where the alternative is this plan): this is the plan a
+    # single job gets, pinned here so that every step of the bench is that job.  --n_boot / --block vary the job.
     "emboot": dict(n_ind=1000, n_sites=100_000, indep=False, evol_model=2, seed=3, n_boot=100, block=10,
                    options={"boot_partials": 0}),
 }

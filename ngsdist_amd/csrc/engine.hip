@@ -233,7 +233,14 @@ template <typename T>
 static int dev_alloc(ngd_engine *e, T **p, uint64_t count, bool zero) {
   *p = nullptr;
   if (!count) return NGD_OK;
+  // NGD_TRACE_ALLOC=1: what every allocation of 64 MiB and more costs (the driver clears memory other processes have used
+  // as it hands it out: seconds for tens of GB on a device that has just been busy, DESIGN.md section 3 "K0")
+  static const bool trace = getenv("NGD_TRACE_ALLOC") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+  if (trace && count * sizeof(T) >= (64u << 20))
+    fprintf(stderr, "> alloc: hipMalloc of %.2f GB took %.3f s\n", (double)(count * sizeof(T)) / 1e9,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   e->dev_bytes += count * sizeof(T);
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), e->st));
   return NGD_OK;
@@ -1897,7 +1904,12 @@ static int partials_impl(ngd_engine *e, const uint32_t *mult /*[n_rep][n_blocks]
       const double ps = (double)e->n_owned_pairs * (double)n_eff;
       const bool table = e->kernel == NGD_KERNEL_EM_TABLE;
       const double pass_ms = mfma ? ps / 1.05e10 : table ? ps / 1.9e8 : e->kernel == NGD_KERNEL_EM_FAST ? ps / 7.5e7 : ps / 3.8e6;
+      // (the table-driven kernel's spilled-terms plan, em_spill_impl: ONE EM pass + a contraction whatever the replicate
+      // count -- [measured, round 6] without this term the engine bought an 84 GB slab for a single job of 10 000 blocks of
+      // 10 sites, 3 ms on a device nobody has used and 5.8 s on one that has just been busy)
+      const bool spill = table && e->em_shape == 0 && e->opt_em_spill && n_rep >= (e->opt_em_spill == 2 ? 2u : 3u);
       const double alt_ms = mfma ? 0.75 * pass_ms * n_rep
+                            : spill ? 1.1 * pass_ms
                             : table ? std::min(0.65 * pass_ms * n_rep, 2.9 * pass_ms * ((n_rep + 15) / 16))
                                     : 1.1 * pass_ms * ((n_rep + 15) / 16);
       if (e->rent_B != block_size || e->rent_blocks != n_blocks) {
