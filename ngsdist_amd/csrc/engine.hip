@@ -1467,6 +1467,40 @@ static int fixup_by_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, doubl
   return NGD_OK;
 }
 
+// The same for the per-block partial results of a bootstrap job whose blocks are whole k-groups: EVERY entry of the slab is
+// formed again by the two-operand arithmetic, the scratch images made for a range of whole slices at a time (in eights: the
+// XCD deal of accum_mfma.hip) and handed to the kernel moved back by the range's first k-group, as launch_accumulate() does
+// for ngd_config.single_image = 1.  The replicates are then reduced from the slab again (partials_impl).
+static int fixup_partials_by_pass(ngd_engine *e, uint64_t s_hi) {
+  const ngd_geom &g = e->g;
+  const uint64_t kstride = (uint64_t)g.n_ig * 64;
+  const uint64_t kg_lim = std::min<uint64_t>(g.n_kg, 3 * s_hi / 4);
+  const uint64_t per_slice = e->boot_per_slice;
+  const uint32_t n_ks = e->boot_nks;
+  if (!per_slice || !n_ks || n_ks % 8) return fail(NGD_E_HIP, "fix-up pass: internal -- the partial results' slices are not in eights");
+  const uint64_t span = std::max<uint64_t>(8 * per_slice, ((uint64_t)1 << 30) / (kstride * 8));  // ~1 GiB per scratch image
+  auto kg0 = [&](uint64_t ks) { return ks * per_slice; };
+  auto kg1 = [&](uint64_t ks) { return std::min<uint64_t>(kg_lim, (ks + 1) * per_slice); };
+  for (uint32_t ks0 = 0; ks0 < n_ks;) {
+    uint32_t n = 8;
+    while (ks0 + n < n_ks && kg1(ks0 + n + 7) - kg0(ks0) <= span && kg0(ks0 + n) < kg_lim) n += 8;
+    n = std::min(n, n_ks - ks0);
+    const uint64_t lo = std::min<uint64_t>(kg0(ks0), kg_lim), hi = std::max(lo, kg1(ks0 + n - 1));
+    const uint64_t need = (hi - lo + NGD_KG_TAIL) * kstride;
+    int rc = ensure_cap(e, &e->fix_p, &e->cap_fix_p, need);
+    if (rc) return rc;
+    if ((rc = ensure_cap(e, &e->fix_q, &e->cap_fix_q, need))) return rc;
+    ngd_launch_pq_range(e->st, g, e->sc, e->PA, e->SM, nullptr, lo, std::min<uint64_t>(hi + NGD_KG_TAIL, g.n_kg + NGD_KG_TAIL), e->fix_p, e->fix_q);
+    const double *p_back = reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(e->fix_p) - lo * kstride * sizeof(double));
+    const double *q_back = reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(e->fix_q) - lo * kstride * sizeof(double));
+    ngd_launch_accum_mfma(e->st, g, p_back, q_back, nullptr, nullptr, e->d_jobs, e->n_wg, e->exact_shapes, e->wg_waves, n, per_slice,
+                          kg_lim, 0, 0, e->slab_boot, e->d_clk, ks0);
+    HIPCHK(hipGetLastError());
+    ks0 += n;
+  }
+  return NGD_OK;
+}
+
 static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *d_sum, uint64_t sites_per_slice,
                       uint32_t n_slab_slices, bool *patched, const unsigned long long *d_cnt = nullptr, double thr = 0.0) {
   if (patched) *patched = false;
@@ -1535,6 +1569,30 @@ static int fixup_pass(ngd_engine *e, const uint32_t *ws, uint64_t s_hi, double *
     const double t_pass = 6.0 * (double)e->n_owned_pairs * (double)s_hi / 55e12 + 80.0 * (double)e->g.n_pad * (double)s_hi / 2.4e12 + 2e-3;
     if (t_tiles > t_pass) {
       int rc = fixup_by_pass(e, ws, s_hi, d_sum, d_cnt, thr);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(t1, e->st));
+      HIPCHK(hipStreamSynchronize(e->st));
+      if (int rf = mfma_fault(e)) return rf;
+      float ms = 0;
+      hipEventElapsedTime(&ms, t0, t1);
+      e->fix_info.ms += ms;
+      e->fix_info.recomputed += all ? e->n_owned_pairs : n;
+      e->fix_info.by_pass += 1;
+      if (patched) *patched = true;
+      return NGD_OK;
+    }
+  }
+  // Per-block partial results (whole k-groups per block): where the noted tiles would cost more than the whole slab again
+  // in the two-operand arithmetic, the whole slab it is (round 6; the tiles: 0.8 s for a data set of clones at cfg 3's size)
+  if (!d_sum && e->kernel == NGD_KERNEL_MFMA && e->exact_shapes == 0 && e->slab_boot && e->boot_per_slice &&
+      e->boot_B % 4 == 0 && (uint64_t)e->boot_per_slice * 4 == sites_per_slice * 3) {
+    const double t_tiles = ((double)tiles.size() * 256.0 + (double)singles.size() * 60.0) * (double)s_hi / 6.5e11;
+    const double t_pass = 6.0 * (double)e->n_owned_pairs * (double)s_hi / 50e12 + 80.0 * (double)e->g.n_pad * (double)s_hi / 2.4e12 + 2e-3;
+    // (tests only, NGD_ENABLE_TEST_HOOKS=1: NGD_TEST_FIX_PARTIALS = "pass" / "tiles" takes the choice away from the estimate)
+    const char *forced = (getenv("NGD_ENABLE_TEST_HOOKS") && atoi(getenv("NGD_ENABLE_TEST_HOOKS"))) ? getenv("NGD_TEST_FIX_PARTIALS") : nullptr;
+    const bool by_pass = forced ? forced[0] == 'p' : t_tiles > t_pass;
+    if (by_pass) {
+      int rc = fixup_partials_by_pass(e, s_hi);
       if (rc) return rc;
       HIPCHK(hipEventRecord(t1, e->st));
       HIPCHK(hipStreamSynchronize(e->st));

@@ -478,6 +478,48 @@ def test_job_in_one_call_when_the_fixup_pass_patches_the_partial_results(pairwis
     assert np.array_equal(Cn[0][idx], co) and rel_err(S[0][idx], so) < RTOL
 
 
+@pytest.mark.parametrize("pairwise_del", [False, True])
+@pytest.mark.parametrize("block_size,n_sites", [(100, 4000), (8, 1000), (1000, 5000)])
+def test_fixup_of_per_block_partial_results_by_one_more_pass(pairwise_del, block_size, n_sites, monkeypatch):
+    """a bootstrap job by per-block partial results on a one-image engine whose data hold clusters of nearly identical
+    individuals: the noted pairs' slab entries are recomputed tile by tile -- or, where that would cost more, the WHOLE slab once
+    more in the two-operand arithmetic from scratch images made a range of whole slices at a time (fixup_partials_by_pass).
+    Both routes, forced through the test hook: the same sums as a two-image engine to 1e-9 and the oracle's on the clones."""
+    monkeypatch.setenv("NGD_ENABLE_TEST_HOOKS", "1")
+    n_ind, n_rep = 400, 5
+    rng = np.random.default_rng(block_size)
+    p = O.synth_indmajor(9, n_ind, n_sites, miss_frac=0.05 if pairwise_del else 0.0)
+    g = rng.integers(0, 3, size=n_sites)
+    clones = [5, 6, 7, 200, 201, 399]
+    for k in clones:
+        q = 1e-12 * (1 + rng.random((n_sites, 3)))
+        q[np.arange(n_sites), g] = 0
+        q[np.arange(n_sites), g] = 1 - q.sum(axis=1)
+        p[k] = q
+    n_eff = n_sites - n_sites % block_size
+    maps = np.stack([N().Taus(r + 1).block_map(n_eff // block_size) for r in range(n_rep)])
+    with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, kernel="mfma", single_image=3) as e:
+        e.set_option("boot_partials", 2)
+        S2, C2 = e.upload_ind_major(p).commit().run_job(maps, block_size)
+    got = {}
+    for route in ("pass", "tiles"):
+        monkeypatch.setenv("NGD_TEST_FIX_PARTIALS", route)
+        with N().Engine(n_ind, n_sites, pairwise_del=pairwise_del, kernel="mfma", single_image=2) as e:
+            e.set_option("boot_partials", 2)
+            S, Cn = e.upload_ind_major(p).commit().run_job(maps, block_size)
+            f = e.fixup()
+        assert f["recomputed"] >= 15 and f["skipped"] == 0 and f["by_pass"] == (1 if route == "pass" else 0), (route, f)
+        assert np.array_equal(Cn, C2)
+        fin = C2 > 0
+        assert rel_err(S[fin], S2[fin]) < RTOL, route
+        got[route] = S
+    sub = np.array(clones + [11])
+    so, co = O.all_pairs(np.ascontiguousarray(p[sub]), pairwise_del=pairwise_del, n_threads=8)
+    idx = [N()._lib.load().ngd_pair_index(n_ind, int(min(a, b)), int(max(a, b))) for k, a in enumerate(sub) for b in sub[k + 1:]]
+    for route in got:
+        assert rel_err(got[route][0][idx], so) < RTOL, route
+
+
 def test_job_in_one_call_wants_whole_matrices():
     """an engine that owns a share of the pairs holds part of every matrix: the tail cannot be applied to it"""
     p = O.synth_indmajor(1, 140, 64)
