@@ -354,6 +354,8 @@ typedef struct ngd_fixup_info {
   uint64_t by_pass; /* recomputations that went the whole-matrix way: so many noted pairs that ONE more pass in the    */
                     /* two-image arithmetic over scratch images (a pass and a half: ~70 ms at 1000 x 1e6) was cheaper  */
                     /* than their tiles -- a data set of clones; the noted pairs take its sums, the others keep theirs */
+                    /* (a bootstrap job's per-block partial results, blocks of whole k-groups: EVERY entry of the slab  */
+                    /* is formed again that way, all pairs take the two-image engine's bits)                           */
 } ngd_fixup_info;
 int ngd_last_fixup(const ngd_engine *e, ngd_fixup_info *info);
 /* The accumulation phase of the last run that took the spilled-terms plan (EM path, bootstrap blocks too small for
